@@ -1,0 +1,313 @@
+"""fp32 PyTorch-CPU restatement of the reference hot path (TEST INFRASTRUCTURE).
+
+Written as explicit math on a plain {reference state_dict key: tensor} mapping,
+so that it shares no code with the product modules and none with torch's
+nn.TransformerEncoderLayer.  Pinned by tests/golden/model_*.json, which
+tools/make_golden.py produced from the imported reference classes.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this file (see oracle/__init__.py).
+
+Reference citations (relative to /root/reference unless prefixed torch:):
+  tokenizers   src/tokenizers/_1D/hilbert_embedding1D.py:30-44 (= morton),
+               src/tokenizers/_1D/zigzag_embedding1D.py:30-39,
+               src/tokenizers/multiscale/multi_hilbert.py:74-84
+  mixer        src/models/vit.py:268-273
+  encoder      src/models/vit.py:197-206,241 -> torch:nn/modules/transformer.py:951-982
+               (post-norm, relu, eps 1e-5), torch:nn/functional.py:5822-5833,6623-6637
+  head         src/models/vit.py:289-292,303-319
+  forward      src/models/vit.py:366-385 (2-D), :445-458 (1-D)
+  loss         main.py:45-51
+  step         src/training/train.py:153-167, main.py:288-289
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import curves as _curves
+
+
+@dataclass
+class OracleConfig:
+    tokenizer: str          # "hilbert1d" | "morton1d" | "raster1d" | "sfc"
+    img_size: int
+    patch_size: int         # pixels per token (1-D tokenizers) or group size g ("sfc")
+    in_channels: int
+    embed_dim: int
+    depth: int
+    n_heads: int
+    mlp_dim: int
+    num_classes: int
+    variant: str = "1d"     # "1d" = VisionTransformer1D (with mixer), "2d" = VisionTransformer
+    pre_patch_size: int = 1  # p of SFCEmbedding1D
+    curve: str = "hilbert"   # curve of SFCEmbedding1D
+
+    @property
+    def n_patches(self):
+        if self.tokenizer == "sfc":
+            grid = self.img_size // self.pre_patch_size
+            return grid * grid // self.patch_size
+        return self.img_size * self.img_size // self.patch_size
+
+    @property
+    def input_dim(self):
+        if self.tokenizer == "sfc":
+            return self.in_channels * self.pre_patch_size ** 2 * self.patch_size
+        return self.in_channels * self.patch_size
+
+    @property
+    def table_key(self):
+        return {"hilbert1d": "hilbert_indices", "morton1d": "z_indices",
+                "raster1d": None, "sfc": "sfc_indices"}[self.tokenizer]
+
+
+# ----------------------------------------------------------------------------
+# tokenizers
+# ----------------------------------------------------------------------------
+def curve_buffer(cfg):
+    """The registered index buffer of the tokenizer, as the reference builds it."""
+    if cfg.tokenizer == "hilbert1d":
+        return torch.from_numpy(_curves.embed_and_prune_sfc("hilbert", cfg.img_size, cfg.img_size))
+    if cfg.tokenizer == "morton1d":
+        return torch.from_numpy(_curves.embed_and_prune_sfc("z", cfg.img_size, cfg.img_size))
+    if cfg.tokenizer == "sfc":
+        grid = cfg.img_size // cfg.pre_patch_size
+        return torch.from_numpy(_curves.flat_table(cfg.curve, grid))
+    return None
+
+
+def tokens_1d(x, idx_rc, patch_size):
+    """hilbert_embedding1D.py:36-40: gather along the curve, 'b c n -> b n c',
+    reshape to [B, N, ps*C] (feature index = k*C + c)."""
+    b, c = x.shape[0], x.shape[1]
+    g = x[:, :, idx_rc[:, 0], idx_rc[:, 1]]          # [B, C, H*W]
+    g = g.permute(0, 2, 1)                            # [B, H*W, C]
+    return g.reshape(b, -1, patch_size * c)
+
+
+def tokens_raster(x, patch_size):
+    """zigzag_embedding1D.py:36-38."""
+    b, c = x.shape[0], x.shape[1]
+    g = x.flatten(2).transpose(1, 2)
+    return g.reshape(b, -1, patch_size * c)
+
+
+def tokens_sfc(x, flat_idx, p, g):
+    """multi_hilbert.py:78-82: p x p pre-patches with feature order (p1 p2 c),
+    permuted by the flat table, g consecutive pre-patches per token."""
+    b, c, h, w = x.shape
+    gh, gw = h // p, w // p
+    t = x.reshape(b, c, gh, p, gw, p).permute(0, 2, 4, 3, 5, 1)   # b h w p1 p2 c
+    t = t.reshape(b, gh * gw, p * p * c)
+    t = t[:, flat_idx]
+    return t.reshape(b, gh * gw // g, g * p * p * c)
+
+
+def tokenize(x, sd, cfg, prefix="patch_embed."):
+    if cfg.tokenizer in ("hilbert1d", "morton1d"):
+        t = tokens_1d(x, sd[prefix + cfg.table_key], cfg.patch_size)
+    elif cfg.tokenizer == "raster1d":
+        t = tokens_raster(x, cfg.patch_size)
+    elif cfg.tokenizer == "sfc":
+        t = tokens_sfc(x, sd[prefix + "sfc_indices"], cfg.pre_patch_size, cfg.patch_size)
+    else:
+        raise ValueError(cfg.tokenizer)
+    return t @ sd[prefix + "proj.weight"].t() + sd[prefix + "proj.bias"]
+
+
+# ----------------------------------------------------------------------------
+# blocks
+# ----------------------------------------------------------------------------
+def layer_norm(x, w, b, eps=1e-5):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)      # biased
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def gelu_erf(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def mixer_block(x, sd, prefix="mlp_mixer."):
+    """vit.py:272: x + channel_mix(channel_mix_ln(x)); the token-mix branch is
+    commented out in the reference (:269-271) and its parameters are unused."""
+    z = layer_norm(x, sd[prefix + "channel_mix_ln.weight"], sd[prefix + "channel_mix_ln.bias"])
+    h = gelu_erf(z @ sd[prefix + "channel_mix.0.weight"].t() + sd[prefix + "channel_mix.0.bias"])
+    return x + h @ sd[prefix + "channel_mix.2.weight"].t() + sd[prefix + "channel_mix.2.bias"]
+
+
+def attention(x, w_in, b_in, w_out, b_out, n_heads):
+    b, n, d = x.shape
+    hd = d // n_heads
+    qkv = x @ w_in.t() + b_in
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    q = q.reshape(b, n, n_heads, hd).transpose(1, 2)
+    k = k.reshape(b, n, n_heads, hd).transpose(1, 2)
+    v = v.reshape(b, n, n_heads, hd).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(b, n, d)
+    return o @ w_out.t() + b_out
+
+
+def encoder_layer(x, sd, prefix, n_heads):
+    """Post-norm layer, eval mode (dropout off): torch:nn/modules/transformer.py:951-958."""
+    a = attention(x, sd[prefix + "self_attn.in_proj_weight"], sd[prefix + "self_attn.in_proj_bias"],
+                  sd[prefix + "self_attn.out_proj.weight"], sd[prefix + "self_attn.out_proj.bias"],
+                  n_heads)
+    x = layer_norm(x + a, sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"])
+    f = torch.relu(x @ sd[prefix + "linear1.weight"].t() + sd[prefix + "linear1.bias"])
+    f = f @ sd[prefix + "linear2.weight"].t() + sd[prefix + "linear2.bias"]
+    return layer_norm(x + f, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"])
+
+
+def head(x, sd, prefix="mlp_head."):
+    """vit.py:303-319 with n_layers=2: LN -> FactorisedLinear -> GELU -> (Dropout) -> Linear."""
+    z = layer_norm(x, sd[prefix + "0.weight"], sd[prefix + "0.bias"])
+    h = torch.einsum("bnd,rd->bnr", z, sd[prefix + "1.W_emb"])
+    y = torch.einsum("bnr,onr->bo", h, sd[prefix + "1.W_seq"])
+    y = gelu_erf(y)
+    return y @ sd[prefix + "4.weight"].t() + sd[prefix + "4.bias"]
+
+
+def forward(x, sd, cfg, return_intermediates=False):
+    inter = {}
+    t = tokenize(x, sd, cfg)
+    inter["tokens"] = t
+    if cfg.variant == "1d":
+        t = mixer_block(t, sd)
+        inter["mixer"] = t
+    for layer in range(cfg.depth):
+        t = encoder_layer(t, sd, f"encoder.transformer.layers.{layer}.", cfg.n_heads)
+    inter["encoded"] = t
+    logits = head(t, sd)
+    return (logits, inter) if return_intermediates else logits
+
+
+def soft_target_ce(logits, targets):
+    """main.py:49-51."""
+    return -(targets * torch.log_softmax(logits, dim=-1)).sum(-1).mean()
+
+
+# ----------------------------------------------------------------------------
+# state
+# ----------------------------------------------------------------------------
+def state_shapes(cfg):
+    """Reference state_dict keys -> shapes, duplicates included."""
+    d, n, f, c = cfg.embed_dim, cfg.n_patches, cfg.mlp_dim, cfg.num_classes
+    s = {}
+    pe = {}
+    if cfg.tokenizer in ("hilbert1d", "morton1d"):
+        pe[cfg.table_key] = (cfg.img_size ** 2, 2)
+    elif cfg.tokenizer == "sfc":
+        pe["sfc_indices"] = ((cfg.img_size // cfg.pre_patch_size) ** 2,)
+    pe["proj.weight"] = (d, cfg.input_dim)
+    pe["proj.bias"] = (d,)
+    for k, v in pe.items():
+        s["patch_embed." + k] = v
+    if cfg.variant == "1d":
+        m = "mlp_mixer."
+        s[m + "token_mix_ln.weight"] = (d,)
+        s[m + "token_mix_ln.bias"] = (d,)
+        s[m + "channel_mix_ln.weight"] = (d,)
+        s[m + "channel_mix_ln.bias"] = (d,)
+        s[m + "token_mix.0.weight"] = (2 * d, n)
+        s[m + "token_mix.0.bias"] = (2 * d,)
+        s[m + "token_mix.2.weight"] = (n, 2 * d)
+        s[m + "token_mix.2.bias"] = (n,)
+        s[m + "channel_mix.0.weight"] = (2 * d, d)
+        s[m + "channel_mix.0.bias"] = (2 * d,)
+        s[m + "channel_mix.2.weight"] = (d, 2 * d)
+        s[m + "channel_mix.2.bias"] = (d,)
+    for layer in range(cfg.depth):
+        p = f"encoder.transformer.layers.{layer}."
+        s[p + "self_attn.in_proj_weight"] = (3 * d, d)
+        s[p + "self_attn.in_proj_bias"] = (3 * d,)
+        s[p + "self_attn.out_proj.weight"] = (d, d)
+        s[p + "self_attn.out_proj.bias"] = (d,)
+        s[p + "linear1.weight"] = (f, d)
+        s[p + "linear1.bias"] = (f,)
+        s[p + "linear2.weight"] = (d, f)
+        s[p + "linear2.bias"] = (d,)
+        s[p + "norm1.weight"] = (d,)
+        s[p + "norm1.bias"] = (d,)
+        s[p + "norm2.weight"] = (d,)
+        s[p + "norm2.bias"] = (d,)
+    for k, v in pe.items():
+        s["encoder.to_patch_embedding." + k] = v       # vit.py:221 (same tensors)
+    s["mlp_head.0.weight"] = (d,)
+    s["mlp_head.0.bias"] = (d,)
+    s["mlp_head.1.W_emb"] = (64, d)
+    s["mlp_head.1.W_seq"] = (2 * d, n, 64)
+    s["mlp_head.4.weight"] = (c, 2 * d)
+    s["mlp_head.4.bias"] = (c,)
+    return s
+
+
+def formula_state(cfg):
+    """Formula-valued fp32 state for `cfg` (curve buffers from the C oracle)."""
+    from . import formula
+    buf = curve_buffer(cfg)
+    sd = {}
+    for k, shape in state_shapes(cfg).items():
+        if k.startswith("encoder.to_patch_embedding."):
+            continue
+        if cfg.table_key and k.endswith(cfg.table_key):
+            sd[k] = buf.clone()
+        else:
+            sd[k] = formula.param_value(k, shape)
+    for k in list(sd):
+        if k.startswith("patch_embed."):
+            sd["encoder.to_patch_embedding." + k[len("patch_embed."):]] = sd[k]
+    return sd
+
+
+def random_state(cfg, seed=0, dtype=torch.float32):
+    """Random-init fp32 state of the right shapes (for CPU-baseline timing only;
+    the init distribution is not the reference's)."""
+    g = torch.Generator().manual_seed(seed)
+    buf = curve_buffer(cfg)
+    sd = {}
+    for k, shape in state_shapes(cfg).items():
+        if k.startswith("encoder.to_patch_embedding."):
+            continue
+        if cfg.table_key and k.endswith(cfg.table_key):
+            sd[k] = buf.clone()
+        elif k.endswith("weight") and len(shape) == 1:
+            sd[k] = torch.ones(shape, dtype=dtype)
+        elif len(shape) == 1:
+            sd[k] = torch.zeros(shape, dtype=dtype)
+        else:
+            fan_in = 1
+            for v in shape[1:]:
+                fan_in *= v
+            sd[k] = (torch.randn(shape, generator=g, dtype=dtype) / math.sqrt(fan_in))
+    return sd
+
+
+UNUSED_PREFIXES = ("mlp_mixer.token_mix.", "mlp_mixer.token_mix_ln.")
+
+
+def trainable(sd):
+    """Leaf fp32 tensors that receive a gradient (token-mix params never do, vit.py:269-272)."""
+    out = {}
+    for k, v in sd.items():
+        if not torch.is_floating_point(v) or k.startswith("encoder.to_patch_embedding."):
+            continue
+        out[k] = v
+    return out
+
+
+def train_step(x, targets, sd, cfg, opt, clip=1.0):
+    """One step with the semantics of train.py:153-167 (no AMP on CPU, fp32):
+    zero_grad -> forward -> soft-target CE -> backward -> clip_grad_norm_(1.0) ->
+    AdamW.step.  `sd` holds leaf tensors with requires_grad=True for trainable keys."""
+    opt.zero_grad()
+    logits = forward(x, sd, cfg)
+    loss = soft_target_ce(logits, targets)
+    loss.backward()
+    params = [p for p in opt.param_groups[0]["params"]]
+    torch.nn.utils.clip_grad_norm_(params, clip, foreach=False)
+    opt.step()
+    return loss.detach(), logits.detach()

@@ -1,0 +1,96 @@
+"""The oracle (oracle/) against the fixtures generated from the imported reference.
+
+CPU only.  These tests pin the checker itself: every later parity test compares
+the HIP path with this oracle."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import curves as ocurves
+from oracle import formula, vit_oracle
+from oracle.cases import MODEL_CASES, CURVE_KINDS, CURVE_SMALL_N, CURVE_SHA_N
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    return np.load(os.path.join(golden_dir, "curves_small.npz"))
+
+
+@pytest.fixture(scope="module")
+def sha(golden_dir):
+    with open(os.path.join(golden_dir, "curves_sha.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("kind", CURVE_KINDS)
+@pytest.mark.parametrize("n", CURVE_SMALL_N)
+def test_curve_tables_small(kind, n, small):
+    got = ocurves.flat_table(kind, n).astype(np.int32)
+    assert np.array_equal(got, small[f"{kind}_{n}"])          # bit-exact index work
+    assert sorted(got.tolist()) == list(range(n * n))
+
+
+@pytest.mark.parametrize("kind", ("hilbert", "z"))
+@pytest.mark.parametrize("n", CURVE_SHA_N)
+def test_curve_tables_full_size(kind, n, small, sha):
+    got = ocurves.flat_table(kind, n).astype(np.int32)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == sha[f"{kind}_{n}"]
+    assert np.array_equal(got[:64], small[f"{kind}_{n}_head"])
+    assert np.array_equal(got[-64:], small[f"{kind}_{n}_tail"])
+
+
+def test_survey_known_answers(sha):
+    # SURVEY.md App. A.4 (sha256[:16] of the int32 flat table)
+    known = {"hilbert_14": "2e4b9f149c3d0106", "hilbert_224": "10321c9c915a31e7",
+             "hilbert_384": "2d962e4b4ce7c417", "z_14": "2eb5979ae01badf8",
+             "z_224": "c8df515ee1a560ba", "z_384": "34ded228fe3ad441",
+             "moore_24": "00db52e7042ea7f6", "peano_32": "5936897a30db34a5"}
+    for k, v in known.items():
+        assert sha[k][:16] == v
+
+
+def test_state_manifest(golden_dir):
+    with open(os.path.join(golden_dir, "state_manifest.json")) as f:
+        manifest = json.load(f)
+    for name, (cfg, _) in MODEL_CASES.items():
+        shapes = vit_oracle.state_shapes(cfg)
+        ref = {k: tuple(v[0]) for k, v in manifest[name].items()}
+        assert shapes == ref, name
+
+
+@pytest.mark.parametrize("name", sorted(MODEL_CASES))
+def test_model_against_reference_fixture(name, golden_dir):
+    cfg, batch = MODEL_CASES[name]
+    with open(os.path.join(golden_dir, f"model_{name}.json")) as f:
+        gold = json.load(f)
+    sd = vit_oracle.formula_state(cfg)
+    leaves = {}
+    for k, v in vit_oracle.trainable(sd).items():
+        v.requires_grad_(True)
+        leaves[k] = v
+    x = formula.image_batch(batch, cfg.in_channels, cfg.img_size, cfg.img_size)
+    tgt = formula.soft_targets(batch, cfg.num_classes)
+    logits, inter = vit_oracle.forward(x, sd, cfg, return_intermediates=True)
+    loss = vit_oracle.soft_target_ce(logits, tgt)
+    loss.backward()
+    # fp32 vs fp32, different op order only: tight tolerances
+    ref_logits = torch.tensor(gold["logits"], dtype=torch.float64)
+    assert torch.allclose(logits.detach().double(), ref_logits, rtol=1e-4, atol=2e-6)
+    assert abs(float(loss.detach()) - gold["loss"]) < 1e-5
+    tok = inter["tokens"].detach().flatten()
+    got = torch.stack([tok[i] for i in gold["tokens_sample_idx"]]).double()
+    assert torch.allclose(got, torch.tensor(gold["tokens_sample"]).double(), rtol=1e-4, atol=1e-5)
+    assert abs(float(inter["tokens"].detach().double().norm()) - gold["tokens_l2"]) < 1e-3 * gold["tokens_l2"]
+    for k, g in gold["grads"].items():
+        if g is None:
+            assert leaves[k].grad is None, k        # token-mix params never get a grad
+            continue
+        mine = leaves[k].grad.flatten().double()
+        assert abs(float(mine.norm()) - g["l2"]) <= 2e-4 * g["l2"] + 1e-9, k
+        got = torch.stack([mine[i] for i in g["idx"]])
+        assert torch.allclose(got, torch.tensor(g["val"]).double(), rtol=2e-3,
+                              atol=2e-4 * g["l2"] / max(1.0, mine.numel() ** 0.5) + 1e-9), k
