@@ -1,0 +1,214 @@
+/*
+ * sfcvit.h -- C ABI of the MI355X (gfx950) SFC-ViT hot path.
+ *
+ * The reference (RemcoHoger/Space-Filling-Curves-for-Vision-Transformers) is pure
+ * Python on PyTorch and has no FFI of its own: these entry points
+ * are what a binding for the path would bind.  Each one names the reference
+ * interface it replaces (paths relative to the reference root; `torch:` = the
+ * installed torch the reference calls into).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  Unless marked HOST every
+ *     pointer is a device (HBM) pointer and must be 16-byte aligned.
+ *   - bf16 tensors are passed as `const void*` to raw bf16 bits, row-major.
+ *   - `stream` is a hipStream_t (NULL = default stream).  No entry point
+ *     synchronises, allocates or copies to the host: all are graph-capturable.
+ *   - return value: 0 = launched / done, nonzero = rejected (see sfcvit_last_error()).
+ *     Nothing is launched when an argument check fails.
+ *   - inputs are never written; outputs are fully overwritten.
+ */
+#ifndef SFCVIT_H
+#define SFCVIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFCVIT_ABI_VERSION 1
+
+enum sfcvit_status {
+    SFCVIT_OK = 0,
+    SFCVIT_EINVAL = 1,   /* bad argument (shape, alignment, enum) */
+    SFCVIT_ELAUNCH = 2,  /* HIP reported an error at launch */
+    SFCVIT_ENODEV = 3    /* no usable gfx950 device */
+};
+
+int sfcvit_abi_version(void);
+/* HOST: message of the last failing call on this thread ("" if none). */
+const char *sfcvit_last_error(void);
+/* HOST: number of visible HIP devices, <0 on error (does not create a context). */
+int sfcvit_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Curve index tables (host, integer, bit-exact with the reference)
+ * ---------------------------------------------------------------------- */
+enum sfcvit_curve {
+    SFCVIT_CURVE_HILBERT = 0, /* src/curves/space_filling_curves.py:168-202 */
+    SFCVIT_CURVE_Z = 1,       /* :134-165 */
+    SFCVIT_CURVE_MOORE = 2,   /* :205-251 */
+    SFCVIT_CURVE_PEANO = 3,   /* :74-131  */
+    SFCVIT_CURVE_RASTER = 4   /* identity order (RasterScan1DEmbedding, zigzag_embedding1D.py:30-39) */
+};
+
+/* HOST. embed_and_prune_sfc(curve, n, n) (space_filling_curves.py:471-491) as the
+ * flat table r*n+c that SFCEmbedding1D._sfc_indices builds (multi_hilbert.py:68-72).
+ * out_flat: n*n int32. */
+int sfcvit_curve_table(int curve, int n, int32_t *out_flat);
+/* HOST. Same points as (row, col) int64 pairs: the `hilbert_indices` / `z_indices`
+ * buffers of HilbertEmbedding1D / MortonEmbedding1D (hilbert_embedding1D.py:20-28).
+ * out_rc: n*n*2 int64. */
+int sfcvit_curve_table_rc(int curve, int n, int64_t *out_rc);
+
+/* HOST. Per-token pixel offsets for the fused tokenizer kernel.
+ * Token t of SFCEmbedding1D(img, p, g) (multi_hilbert.py:74-84) is made of
+ * P = g*p*p pixels; pixel kk = gi*p*p + p1*p + p2 is at
+ * (row, col) = ((flat[t*g+gi] / grid)*p + p1, (flat[t*g+gi] % grid)*p + p2), grid = img/p.
+ * The 1-D tokenizers are the case p = 1, g = patch_size with `flat` = r*img+c.
+ * flat: grid*grid int32 (curve table); out_pix: (grid*grid/g) * P int32 = img*img entries. */
+int sfcvit_pixel_table(const int32_t *flat, int img, int p, int g, int32_t *out_pix);
+
+/* ------------------------------------------------------------------------
+ * Fused SFC gather + patchify + linear projection
+ *   replaces HilbertEmbedding1D.forward / MortonEmbedding1D.forward
+ *   (src/tokenizers/_1D/hilbert_embedding1D.py:30-44), RasterScan1DEmbedding.forward
+ *   (zigzag_embedding1D.py:30-39) and SFCEmbedding1D.forward (multi_hilbert.py:74-84).
+ * ---------------------------------------------------------------------- */
+typedef struct sfcvit_patch_embed_args {
+    const void *x;      /* [B, C, H*W] image, fp32 (x_is_bf16 = 0) or bf16 */
+    const int32_t *pix; /* [N, P] pixel offsets (sfcvit_pixel_table), device copy */
+    const void *w;      /* [D, P*C] bf16, feature index = kk*C + c (reference layout) */
+    const void *bias;   /* [D] bf16 or NULL */
+    void *y;            /* fwd: out [B*N, D] bf16 ; bwd: in, dY [B*N, D] bf16 */
+    void *dw;           /* bwd: out [D, P*C] fp32 */
+    void *dbias;        /* bwd: out [D] fp32 (NULL = skip) */
+    void *workspace;    /* sfcvit_patch_embed_workspace(...) bytes, 16-byte aligned */
+    int64_t workspace_bytes;
+    int32_t B, C, HW, N, P, D;
+    int32_t x_is_bf16;
+} sfcvit_patch_embed_args;
+
+/* HOST: workspace bytes for fwd (bwd = 0) / bwd (bwd = 1). */
+int64_t sfcvit_patch_embed_workspace(int B, int C, int N, int P, int D, int bwd);
+
+int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *stream);
+/* dW = sum_{b,t} dY[b,t,:]^T tokens[b,t,:] with the tokens re-gathered from x
+ * (nothing but x is saved for backward); the image receives no gradient. */
+int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *stream);
+
+/* ------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fused epilogue
+ *   replaces nn.Linear forward/backward at every site of the path:
+ *   in_proj / out_proj (torch:nn/functional.py:5822-5833,6632-6637), linear1/linear2
+ *   (torch:nn/modules/transformer.py:980-982), MixerBlock.channel_mix (src/models/vit.py:262-266),
+ *   FactorisedLinear's two einsums (vit.py:289-292) and the classifier (vit.py:319).
+ *
+ *   C[M,N] = epilogue( sum_k A(m,k) * B(n,k) )
+ *   a_kmajor = 0: A is [M, lda] with k contiguous;  1: A is [K, lda] with m contiguous
+ *   b_kmajor = 0: B is [N, ldb] with k contiguous;  1: B is [K, ldb] with n contiguous
+ *   epilogue, in this order (fp32):  v += bias[n];  aux_out[m,n] = bf16(v);
+ *   v = act(v);  v += residual[m,n];  v *= dact(aux_in[m,n]);  C[m,n] = v
+ * ---------------------------------------------------------------------- */
+enum sfcvit_act { SFCVIT_ACT_NONE = 0, SFCVIT_ACT_RELU = 1, SFCVIT_ACT_GELU = 2 };
+/* dact: 0 none; RELU: (aux_in > 0); GELU: gelu'(aux_in) (erf form, nn.GELU default) */
+
+typedef struct sfcvit_gemm_args {
+    const void *a, *b;
+    void *c;
+    const void *bias;      /* [N] bf16 or NULL */
+    const void *residual;  /* [M, ldr] bf16 or NULL */
+    const void *aux_in;    /* [M, ldaux] bf16, needed when dact != 0 */
+    void *aux_out;         /* [M, ldaux] bf16 or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldr, ldaux;
+    int32_t a_kmajor, b_kmajor;
+    int32_t act, dact;
+    int32_t c_is_f32;      /* 0: C is bf16, 1: C is fp32 */
+    int32_t splitk;        /* >1: split K over that many workgroups per tile (weight-gradient
+                              shapes); needs `workspace`, allows no epilogue */
+    void *workspace;       /* fp32 slabs, sfcvit_gemm_workspace(M, N, splitk) bytes */
+    int64_t workspace_bytes;
+} sfcvit_gemm_args;
+
+int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);
+/* HOST: bytes of workspace sfcvit_gemm needs for this split (0 when splitk <= 1). */
+int64_t sfcvit_gemm_workspace(int M, int N, int splitk);
+
+/* Column sums: out[n] = sum_m x[m, n] (bias gradients). x bf16 [M, ld]; out fp32 [N]. */
+int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * LayerNorm (biased variance, affine) -- nn.LayerNorm at norm1/norm2
+ * (torch:nn/modules/transformer.py:951-958), channel_mix_ln (vit.py:254,272), mlp_head.0 (vit.py:303)
+ * ---------------------------------------------------------------------- */
+/* y = (x - mean) * rstd * gamma + beta ; mean, rstd fp32 [M] saved for backward. */
+int sfcvit_layernorm_fwd(const void *x, const void *gamma, const void *beta, void *y,
+                         float *mean, float *rstd, int M, int D, float eps, void *stream);
+/* dx (bf16) ; dgamma, dbeta fp32 [D].  If dx_add != NULL, dx = dx_add + LN-backward
+ * (gradient arriving over the residual branch).  ws: fp32 workspace of
+ * sfcvit_layernorm_bwd_ws(M, D) bytes. */
+int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const float *rstd,
+                         const void *gamma, const void *dx_add, void *dx, float *dgamma,
+                         float *dbeta, int M, int D, void *ws, void *stream);
+int64_t sfcvit_layernorm_bwd_ws(int M, int D);
+
+/* ------------------------------------------------------------------------
+ * Multi-head self-attention core (no mask) on the packed projection
+ *   replaces F.scaled_dot_product_attention as reached from nn.MultiheadAttention
+ *   (torch:nn/functional.py:6623-6631); qkv is the in_proj output [B, N, 3*H*hd]
+ *   with q | k | v in thirds, head h at columns h*hd .. h*hd+hd-1 of each third.
+ * ---------------------------------------------------------------------- */
+typedef struct sfcvit_attn_args {
+    const void *qkv; /* [B, N, 3*H*hd] bf16 */
+    void *out;       /* fwd: out [B, N, H*hd] bf16 ; bwd: in */
+    float *lse;      /* [B, H, N] fp32 log-sum-exp of the scaled scores: fwd out, bwd in */
+    const void *dout; /* bwd: [B, N, H*hd] bf16 */
+    void *dqkv;       /* bwd: out [B, N, 3*H*hd] bf16 */
+    float *delta;     /* bwd: workspace [B, H, N] fp32 */
+    int32_t B, N, H, hd;
+    float scale;      /* 1/sqrt(hd) */
+} sfcvit_attn_args;
+
+int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream);
+int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Elementwise / loss / optimizer
+ * ---------------------------------------------------------------------- */
+/* y = gelu_erf(x) (nn.GELU in MultiLayerPredictor, vit.py:308); bf16, n elements. */
+int sfcvit_gelu_fwd(const void *x, void *y, int64_t n, void *stream);
+/* dx = dy * gelu'(x) */
+int sfcvit_gelu_bwd(const void *dy, const void *x, void *dx, int64_t n, void *stream);
+
+/* SoftTargetCrossEntropy (main.py:45-51), forward and gradient in one pass.
+ * logits bf16 [B, ld] (first C columns used), targets fp32 [B, C];
+ * loss_rows fp32 [B] = -sum_c t*log_softmax ; dlogits bf16 [B, ld] = (softmax*sum_c t - t) * gscale
+ * (columns C..ld-1 are written 0).  The mean over B is gscale = 1/B by the caller. */
+int sfcvit_soft_ce(const void *logits, const float *targets, float *loss_rows, void *dlogits,
+                   int B, int C, int ld, float gscale, void *stream);
+
+/* Sum of squares of a bf16 (is_f32 = 0) or fp32 buffer, accumulated into *out (fp32, device). */
+int sfcvit_sumsq_accum(const void *g, int64_t n, int is_f32, float *out, void *stream);
+
+/* Fused clip_grad_norm_ + AdamW step (src/training/train.py:165-166, main.py:288-289) on a
+ * flat buffer.  clip coefficient = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) is computed on the
+ * device from *sumsq (torch.nn.utils.clip_grad_norm_ semantics).  master: fp32 copy of the
+ * parameters (updated), param: bf16 parameters (rewritten from master), grad bf16,
+ * m, v fp32.  Decoupled weight decay as torch.optim.AdamW. */
+typedef struct sfcvit_adamw_args {
+    void *param;       /* bf16 [n] */
+    float *master;     /* fp32 [n] */
+    const void *grad;  /* bf16 [n] */
+    float *m, *v;      /* fp32 [n] */
+    const float *sumsq; /* device scalar: sum of squares of ALL grads (NULL = no clipping) */
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay, max_norm;
+    int32_t step;      /* 1-based */
+} sfcvit_adamw_args;
+int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFCVIT_H */

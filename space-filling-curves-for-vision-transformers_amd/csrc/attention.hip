@@ -1,0 +1,384 @@
+// Multi-head self-attention core for gfx950, head dim 64, no mask (see
+// sfcvit_attention_fwd / _bwd in include/sfcvit.h).  Flash style: the N x N score
+// matrix never exists in HBM; backward recomputes P from Q, K and the saved
+// log-sum-exp.
+//
+// All products are v_mfma_f32_16x16x32_bf16.  Orientations are chosen so that the
+// accumulator of one product is directly the B operand of the next one
+// ("accumulator tile as the next MFMA's operand", cdna_hip_programming.md §3):
+// a lane owns one query (or key) column and its registers enumerate the
+// contraction index of the following product, so P / dS never cross lanes.
+//
+//   forward   (wave = 16 queries, loop over 64-key blocks staged in LDS)
+//       S^T = K Q^T            A: K rows from LDS (b128)      B: Q from registers
+//       O^T += V^T P^T         A: V^T via ds_read_b64_tr_b16  B: exp(S^T) accumulators
+//   backward, dK/dV kernel (wave = 16 keys, loop over 64-query blocks in LDS)
+//       S = Q K^T, dP = dO V^T A: Q / dO rows from LDS        B: K / V from registers
+//       dV^T += dO^T P, dK^T += Q^T dS   A: tr-reads of dO / Q   B: P / dS accumulators
+//   backward, dQ kernel    (wave = 16 queries, loop over 64-key blocks in LDS)
+//       S^T = K Q^T, dP^T = V dO^T ; dQ^T += K^T dS^T  (A: tr-read of K, B: dS^T)
+#include "common_host.h"
+#include "device_common.h"
+
+namespace sfcvit {
+namespace {
+
+constexpr int HD = 64;
+constexpr int THREADS = 256;
+constexpr int BLK = 64;                 // rows (keys or queries) per LDS block
+constexpr int IMG_BYTES = BLK * HD * 2;  // 8 KiB
+
+// [64 rows][64 cols] bf16 image for transposed reads only: 32-B chunk ^ ((row >> 1) & 3).
+__device__ __forceinline__ int vt_off(int row, int col) {
+    return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + ((col & 15) << 1);
+}
+
+// Stage 64 rows x 64 cols from global (row stride `ld` elements) into an LDS image.
+// Rows >= nvalid are zero-filled.  VT = false: "kc" layout, true: "vt" layout.
+template <bool VT>
+__device__ __forceinline__ void stage64(char *img, const uint16_t *__restrict__ src, int ld, int row0, int nvalid,
+                                        int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int v = tid + THREADS * i;
+        const int r = v >> 3, c16 = v & 7;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (row0 + r < nvalid) val = *reinterpret_cast<const u32x4 *>(src + size_t(row0 + r) * ld + c16 * 8);
+        const int off = VT ? vt_off(r, c16 * 8) : kc_off(r, c16);
+        *reinterpret_cast<u32x4 *>(img + off) = val;
+    }
+}
+
+// A-operand fragment of X^T for a 32-deep contraction over image rows:
+// lane (g, i) gets X[rows r_lo+4g+{0..3}, r_hi+4g+{0..3}][col0 + i].
+template <bool VT>
+__device__ __forceinline__ bf16x8 tr_frag(const char *img, int r_lo, int r_hi, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int col = col0 + 4 * p;
+    const int ra = r_lo + 4 * g + q, rb = r_hi + 4 * g + q;
+    int oa, ob;
+    if (VT) {
+        oa = vt_off(ra, col);
+        ob = vt_off(rb, col);
+    } else {
+        oa = kc_off(ra, col >> 3) + ((col & 7) << 1);
+        ob = kc_off(rb, col >> 3) + ((col & 7) << 1);
+    }
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFCVIT_LDS bf16x4 *)(img + oa));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFCVIT_LDS bf16x4 *)(img + ob));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// Row fragment straight from global: lane (g, i) gets X[row0 + i][32*kk + 8g .. +7].
+__device__ __forceinline__ bf16x8 global_frag(const uint16_t *__restrict__ src, int ld, int row0, int nvalid, int kk,
+                                              int lane) {
+    const int r = row0 + (lane & 15);
+    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < nvalid) z = *reinterpret_cast<const bf16x8 *>(src + size_t(r) * ld + kk * 32 + 8 * (lane >> 4));
+    return z;
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4 &a, const f32x4 &b) {
+    bf16x8 r;
+    r[0] = short(f2bf(a[0])); r[1] = short(f2bf(a[1])); r[2] = short(f2bf(a[2])); r[3] = short(f2bf(a[3]));
+    r[4] = short(f2bf(b[0])); r[5] = short(f2bf(b[1])); r[6] = short(f2bf(b[2])); r[7] = short(f2bf(b[3]));
+    return r;
+}
+
+// reduce over the four 16-lane groups (same lane&15)
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// Store a transposed accumulator: acc[hf][r] = X[row = lane&15][col = 16hf + 4g + r].
+__device__ __forceinline__ void store_rows(uint16_t *__restrict__ dst, int ld, int row, bool valid, const f32x4 (&acc)[4],
+                                           float mul, int lane) {
+    if (!valid) return;
+#pragma unroll
+    for (int hf = 0; hf < 4; hf++) {
+        u32x2 o = {pack2bf(acc[hf][0] * mul, acc[hf][1] * mul), pack2bf(acc[hf][2] * mul, acc[hf][3] * mul)};
+        *reinterpret_cast<u32x2 *>(dst + size_t(row) * ld + 16 * hf + 4 * (lane >> 4)) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void attn_fwd_kernel(const sfcvit_attn_args a) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG_BYTES];
+    char *kimg = smem, *vimg = smem + IMG_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, N = a.N, D = a.H * HD, ld = 3 * D;
+    const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
+    const uint16_t *qp = base, *kp = base + D, *vp = base + 2 * D;
+    const int q0 = blockIdx.x * BLK + wave * 16;
+    const float scale = a.scale;
+
+    bf16x8 qf[2];
+    qf[0] = global_frag(qp, ld, q0, N, 0, lane);
+    qf[1] = global_frag(qp, ld, q0, N, 1, lane);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int hf = 0; hf < 4; hf++) o[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < N; k0 += BLK) {
+        __syncthreads();
+        stage64<false>(kimg, kp, ld, k0, N, tid);
+        stage64<true>(vimg, vp, ld, k0, N, tid);
+        __syncthreads();
+
+        f32x4 s[4];
+#pragma unroll
+        for (int kf = 0; kf < 4; kf++) {
+            s[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++)
+                s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag(kimg, 16 * kf, kk, lane), qf[kk], s[kf], 0, 0, 0);
+        }
+        // s[kf][r] = S^T[key = k0 + 16kf + 4g + r][q = lane & 15]
+        float mb = -INFINITY;
+#pragma unroll
+        for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = k0 + 16 * kf + 4 * (lane >> 4) + r;
+                s[kf][r] = key < N ? s[kf][r] * scale : -INFINITY;
+                mb = fmaxf(mb, s[kf][r]);
+            }
+        mb = group_max(mb);
+        const float m_new = fmaxf(m_run, mb);
+        const float alpha = __expf(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                s[kf][r] = __expf(s[kf][r] - m_new);
+                ls += s[kf][r];
+            }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int hf = 0; hf < 4; hf++) o[hf] *= alpha;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const bf16x8 pf = pack_frag(s[2 * c], s[2 * c + 1]);
+#pragma unroll
+            for (int hf = 0; hf < 4; hf++)
+                o[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<true>(vimg, 32 * c, 32 * c + 16, 16 * hf, lane), pf,
+                                                                o[hf], 0, 0, 0);
+        }
+    }
+    const float l_tot = group_sum(l_run);
+    const int q = q0 + (lane & 15);
+    uint16_t *out = static_cast<uint16_t *>(a.out) + size_t(b) * N * D + h * HD;
+    store_rows(out, D, q, q < N, o, 1.f / l_tot, lane);
+    if (q < N && lane < 16) a.lse[(size_t(b) * a.H + h) * N + q] = m_run + __logf(l_tot);
+}
+
+// ---------------------------------------------------------------------------
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void attn_delta_kernel(const uint16_t *__restrict__ dout,
+                                                             const uint16_t *__restrict__ out, float *__restrict__ delta,
+                                                             int B, int N, int H) {
+    // one 8-lane group per (b, q, h): 8 lanes x 8 elements = 64
+    const int64_t grp = (int64_t(blockIdx.x) * THREADS + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    const int64_t total = int64_t(B) * N * H;
+    float s = 0.f;
+    if (grp < total) {
+        const size_t off = size_t(grp) * HD + sub * 8;   // [B, N, H, hd] is contiguous
+        const u32x4 x = *reinterpret_cast<const u32x4 *>(dout + off), y = *reinterpret_cast<const u32x4 *>(out + off);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            s += bf2f(uint16_t(x[i])) * bf2f(uint16_t(y[i])) + bf2f(uint16_t(x[i] >> 16)) * bf2f(uint16_t(y[i] >> 16));
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (grp < total && sub == 0) {
+        const int64_t bq = grp / H;
+        const int hh = int(grp % H);
+        const int64_t bb = bq / N, qq = bq % N;
+        delta[(bb * H + hh) * N + qq] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward: dK, dV (one workgroup = 64 keys of one (b, h); wave = 16 keys)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(const sfcvit_attn_args a) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG_BYTES + 2 * BLK * 4];
+    char *qimg = smem, *doimg = smem + IMG_BYTES;
+    float *lse_s = reinterpret_cast<float *>(smem + 2 * IMG_BYTES), *del_s = lse_s + BLK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, N = a.N, D = a.H * HD, ld = 3 * D;
+    const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
+    const uint16_t *qp = base, *kp = base + D, *vp = base + 2 * D;
+    const uint16_t *dop = static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD;
+    const float *lse = a.lse + (size_t(b) * a.H + h) * N, *del = a.delta + (size_t(b) * a.H + h) * N;
+    const int key0 = blockIdx.x * BLK + wave * 16;
+    const float scale = a.scale;
+
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+        kf[kk] = global_frag(kp, ld, key0, N, kk, lane);
+        vf[kk] = global_frag(vp, ld, key0, N, kk, lane);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int hf = 0; hf < 4; hf++) dk[hf] = dv[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int q0 = 0; q0 < N; q0 += BLK) {
+        __syncthreads();
+        stage64<false>(qimg, qp, ld, q0, N, tid);
+        stage64<false>(doimg, dop, D, q0, N, tid);
+        if (tid < BLK) {
+            lse_s[tid] = q0 + tid < N ? lse[q0 + tid] : 0.f;
+            del_s[tid] = q0 + tid < N ? del[q0 + tid] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int qf = 2 * c + t;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag(qimg, 16 * qf, kk, lane), kf[kk], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag(doimg, 16 * qf, kk, lane), vf[kk], dp, 0, 0, 0);
+                }
+                // s[r] = S[q = q0 + 16qf + 4g + r][key = key0 + (lane&15)]
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ql = 16 * qf + 4 * (lane >> 4) + r;
+                    const float pv = __expf(s[r] * scale - lse_s[ql]);
+                    p[t][r] = pv;
+                    ds[t][r] = pv * (dp[r] - del_s[ql]) * scale;
+                }
+            }
+            const bf16x8 pf = pack_frag(p[0], p[1]), dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int hf = 0; hf < 4; hf++) {
+                dv[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<false>(doimg, 32 * c, 32 * c + 16, 16 * hf, lane), pf,
+                                                                 dv[hf], 0, 0, 0);
+                dk[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<false>(qimg, 32 * c, 32 * c + 16, 16 * hf, lane), dsf,
+                                                                 dk[hf], 0, 0, 0);
+            }
+        }
+    }
+    const int key = key0 + (lane & 15);
+    uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
+    store_rows(dbase + D, ld, key, key < N, dk, 1.f, lane);
+    store_rows(dbase + 2 * D, ld, key, key < N, dv, 1.f, lane);
+}
+
+// ---------------------------------------------------------------------------
+// backward: dQ (one workgroup = 64 queries of one (b, h); wave = 16 queries)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(const sfcvit_attn_args a) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG_BYTES];
+    char *kimg = smem, *vimg = smem + IMG_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, N = a.N, D = a.H * HD, ld = 3 * D;
+    const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
+    const uint16_t *qp = base, *kp = base + D, *vp = base + 2 * D;
+    const uint16_t *dop = static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD;
+    const int q0 = blockIdx.x * BLK + wave * 16;
+    const int q = q0 + (lane & 15);
+    const float scale = a.scale;
+    const float lse_q = q < N ? a.lse[(size_t(b) * a.H + h) * N + q] : 0.f;
+    const float del_q = q < N ? a.delta[(size_t(b) * a.H + h) * N + q] : 0.f;
+
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+        qf[kk] = global_frag(qp, ld, q0, N, kk, lane);
+        dof[kk] = global_frag(dop, D, q0, N, kk, lane);
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int hf = 0; hf < 4; hf++) dq[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < N; k0 += BLK) {
+        __syncthreads();
+        stage64<false>(kimg, kp, ld, k0, N, tid);
+        stage64<false>(vimg, vp, ld, k0, N, tid);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int kfi = 2 * c + t;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag(kimg, 16 * kfi, kk, lane), qf[kk], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag(vimg, 16 * kfi, kk, lane), dof[kk], dp, 0, 0, 0);
+                }
+                // s[r] = S^T[key = k0 + 16kfi + 4g + r][q]; keys >= N have K = V = 0 and add nothing
+#pragma unroll
+                for (int r = 0; r < 4; r++) ds[t][r] = __expf(s[r] * scale - lse_q) * (dp[r] - del_q) * scale;
+            }
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int hf = 0; hf < 4; hf++)
+                dq[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<false>(kimg, 32 * c, 32 * c + 16, 16 * hf, lane), dsf,
+                                                                 dq[hf], 0, 0, 0);
+        }
+    }
+    uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
+    store_rows(dbase, ld, q, q < N, dq, 1.f, lane);
+}
+
+int check_args(const sfcvit_attn_args *a, const char *what, bool bwd) {
+    if (!a || !a->qkv || !a->out || !a->lse) return fail(SFCVIT_EINVAL, "%s: null pointer", what);
+    if (bwd && (!a->dout || !a->dqkv || !a->delta)) return fail(SFCVIT_EINVAL, "%s: null pointer", what);
+    if (a->hd != HD) return fail(SFCVIT_EINVAL, "%s: head dim %d not supported (this build: 64)", what, a->hd);
+    if (a->B <= 0 || a->N <= 0 || a->H <= 0 || a->B > 65535 || a->H > 65535)
+        return fail(SFCVIT_EINVAL, "%s: B=%d N=%d H=%d", what, a->B, a->N, a->H);
+    if (!aligned16(a->qkv) || !aligned16(a->out) || (bwd && (!aligned16(a->dout) || !aligned16(a->dqkv))))
+        return fail(SFCVIT_EINVAL, "%s: tensors must be 16-byte aligned", what);
+    return SFCVIT_OK;
+}
+
+}  // namespace
+}  // namespace sfcvit
+
+using namespace sfcvit;
+
+extern "C" int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream) {
+    if (int rc = check_args(a, "attention_fwd", false)) return rc;
+    dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a);
+    return check_launch("attention_fwd");
+}
+
+extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
+    if (int rc = check_args(a, "attention_bwd", true)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t groups = int64_t(a->B) * a->N * a->H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(unsigned((groups * 8 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s,
+                       static_cast<const uint16_t *>(a->dout), static_cast<const uint16_t *>(a->out), a->delta, a->B, a->N, a->H);
+    if (int rc = check_launch("attention_bwd delta")) return rc;
+    dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(THREADS), 0, s, *a);
+    if (int rc = check_launch("attention_bwd kv")) return rc;
+    hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(THREADS), 0, s, *a);
+    return check_launch("attention_bwd q");
+}

@@ -1,0 +1,80 @@
+// Device-side helpers for gfx950 (CDNA4): wave = 64 lanes, bf16 MFMA 16x16x32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sfcvit {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // one 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define SFCVIT_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(uint32_t(b) << 16); }
+
+// Round-to-nearest-even fp32 -> bf16; a plain cast lets hipcc pick v_cvt_pk_bf16_f32
+// (NaN stays NaN, MI355X_MICROARCH.md "Correctness boundaries").
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return uint32_t(f2bf(lo)) | (uint32_t(f2bf(hi)) << 16);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- LDS images used by the MFMA kernels ------------------------------------
+// "kc" image: [rows][64] bf16 (128-B rows), k contiguous.  16-B chunk index is
+// XOR-ed with (row >> 1) & 7: conflict-free for ds_write_b128 staging and for the
+// ds_read_b128 fragment reads below (tools/lds_conflicts.py).
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Fragment of 16 rows x 32 k from a kc image: lane holds row (lane&15), k = 8*(lane>>4)+j.
+__device__ __forceinline__ bf16x8 kc_frag(const char *img, int row0, int kk, int lane) {
+    const int row = row0 + (lane & 15);
+    return *reinterpret_cast<const bf16x8 *>(img + kc_off(row, kk * 4 + (lane >> 4)));
+}
+
+// "st" image: [64 k][128 cols] bf16 (256-B rows), cols contiguous (operand stored
+// k-major in memory).  32-B chunk index XOR-ed with (k&3) | ((k>>3)&1)<<2:
+// conflict-free for ds_write_b128 staging and for the transposed reads.
+__device__ __forceinline__ int st_off(int krow, int col) {
+    int c32 = (col >> 4) ^ ((krow & 3) | (((krow >> 3) & 1) << 2));
+    return krow * 256 + (c32 << 5) + ((col & 15) << 1);
+}
+
+// Same fragment (16 cols x 32 k, lane holds col (lane&15), k = 8*(lane>>4)+j) from an
+// st image via two ds_read_b64_tr_b16 (4 k-rows x 16 cols per 16-lane group each).
+// EXEC must be all ones (cdna_hip_programming.md T10).
+__device__ __forceinline__ bf16x8 st_frag(const char *img, int col0, int kk, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int k0 = kk * 32 + 8 * g + q;
+    const int col = col0 + 4 * p;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFCVIT_LDS bf16x4 *)(img + st_off(k0, col)));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFCVIT_LDS bf16x4 *)(img + st_off(k0 + 4, col)));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// 64-lane butterfly reductions.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace sfcvit

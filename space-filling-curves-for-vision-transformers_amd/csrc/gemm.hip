@@ -1,0 +1,196 @@
+// bf16 MFMA GEMM with fused epilogue for gfx950 (see sfcvit_gemm in include/sfcvit.h).
+//
+//   C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ),  fp32 accumulation.
+//
+// Tile machinery: gemm_core.h.  Operands are staged global -> registers -> LDS (two
+// LDS buffers, one barrier per k-tile; the global loads of tile t+1 are issued before
+// the MFMAs of tile t and written to LDS after them).  Each operand may be stored
+// k-contiguous ("kc" LDS image, ds_read_b128 fragments) or k-major ("st" image,
+// ds_read_b64_tr_b16 fragments), which covers y = x W^T, dx = dy W and dW = dy^T x
+// without any transposed copy in HBM.
+//
+// Weight-gradient shapes (M, N small; K = batch * tokens) have too few output tiles
+// to fill 256 CUs, so K can be split over blockIdx.z: every split stores its fp32
+// tile into its own slab of a caller-provided workspace with plain 16-byte stores
+// and splitk_reduce sums the slabs in a fixed order (bitwise reproducible, no
+// atomics; MI355X_MICROARCH.md "Global float atomics" prices the alternative).
+#include "common_host.h"
+#include "gemm_core.h"
+
+namespace sfcvit {
+namespace {
+
+using namespace gemm_core;
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const sfcvit_gemm_args g, int k_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const uint16_t *A = static_cast<const uint16_t *>(g.a);
+    const uint16_t *B = static_cast<const uint16_t *>(g.b);
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = min(g.K, kbeg + k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x4 acc[4][4];
+    zero_acc(acc);
+
+    Stage sa, sb;
+    load_tile<A_KM>(sa, A, g.lda, m0, g.M, kbeg, kend, tid);
+    load_tile<B_KM>(sb, B, g.ldb, n0, g.N, kbeg, kend, tid);
+    store_tile<A_KM>(sa, smem, tid);
+    store_tile<B_KM>(sb, smem + TILE_BYTES, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; kt++) {
+        const char *ia = smem + (kt & 1) * 2 * TILE_BYTES;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            load_tile<A_KM>(sa, A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
+            load_tile<B_KM>(sb, B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, tid);
+        }
+        mma_tile<A_KM, B_KM>(acc, ia, ia + TILE_BYTES, wm, wn, lane);
+        if (more) {
+            char *oa = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            store_tile<A_KM>(sa, oa, tid);
+            store_tile<B_KM>(sb, oa + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    if (gridDim.z > 1) {
+        store_partial(acc, static_cast<float *>(g.workspace) + size_t(blockIdx.z) * g.M * g.N, g.M, g.N, m0, n0, wm, wn, lane);
+        return;
+    }
+
+    // Epilogue (N % 4 == 0 is checked on the host: a 4-vector is entirely inside or outside).
+    const uint16_t *bias = static_cast<const uint16_t *>(g.bias);
+    const uint16_t *res = static_cast<const uint16_t *>(g.residual);
+    const uint16_t *auxi = static_cast<const uint16_t *>(g.aux_in);
+    uint16_t *auxo = static_cast<uint16_t *>(g.aux_out);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        if (n >= g.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const u32x2 b2 = *reinterpret_cast<const u32x2 *>(bias + n);
+            bv[0] = bf2f(uint16_t(b2[0])); bv[1] = bf2f(uint16_t(b2[0] >> 16));
+            bv[2] = bf2f(uint16_t(b2[1])); bv[3] = bf2f(uint16_t(b2[1] >> 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (m >= g.M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
+            if (auxo) {
+                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                *reinterpret_cast<u32x2 *>(auxo + size_t(m) * g.ldaux + n) = o;
+            }
+            if (g.act == SFCVIT_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            } else if (g.act == SFCVIT_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = gelu_erf(v[r]);
+            }
+            if (res) {
+                const u32x2 r2 = *reinterpret_cast<const u32x2 *>(res + size_t(m) * g.ldr + n);
+                v[0] += bf2f(uint16_t(r2[0])); v[1] += bf2f(uint16_t(r2[0] >> 16));
+                v[2] += bf2f(uint16_t(r2[1])); v[3] += bf2f(uint16_t(r2[1] >> 16));
+            }
+            if (g.dact != SFCVIT_ACT_NONE) {
+                const u32x2 a2 = *reinterpret_cast<const u32x2 *>(auxi + size_t(m) * g.ldaux + n);
+                const float a[4] = {bf2f(uint16_t(a2[0])), bf2f(uint16_t(a2[0] >> 16)), bf2f(uint16_t(a2[1])),
+                                    bf2f(uint16_t(a2[1] >> 16))};
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    v[r] = (g.dact == SFCVIT_ACT_RELU) ? (a[r] > 0.f ? v[r] : 0.f) : v[r] * gelu_erf_grad(a[r]);
+            }
+            if (g.c_is_f32) {
+                *reinterpret_cast<f32x4 *>(static_cast<float *>(g.c) + size_t(m) * g.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                *reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
+// C[m, n] = sum_z slab[z][m][n]; 4 columns per thread.
+__global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ ws, int splits, int M, int N, void *c,
+                                                    int ldc, int c_is_f32) {
+    const int64_t v = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int nv = N >> 2;
+    if (v >= int64_t(M) * nv) return;
+    const int m = int(v / nv), n = int(v % nv) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splits; z++) s += *reinterpret_cast<const f32x4 *>(ws + (size_t(z) * M + m) * N + n);
+    if (c_is_f32) {
+        *reinterpret_cast<f32x4 *>(static_cast<float *>(c) + size_t(m) * ldc + n) = s;
+    } else {
+        u32x2 o = {pack2bf(s[0], s[1]), pack2bf(s[2], s[3])};
+        *reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(c) + size_t(m) * ldc + n) = o;
+    }
+}
+
+}  // namespace
+}  // namespace sfcvit
+
+extern "C" int64_t sfcvit_gemm_workspace(int M, int N, int splitk) {
+    if (splitk <= 1 || M <= 0 || N <= 0) return 0;
+    return int64_t(splitk) * M * N * int64_t(sizeof(float));
+}
+
+extern "C" int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream) {
+    using namespace sfcvit;
+    if (!a || !a->a || !a->b || !a->c) return fail(SFCVIT_EINVAL, "gemm: null operand");
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0) return fail(SFCVIT_EINVAL, "gemm: M=%d N=%d K=%d", a->M, a->N, a->K);
+    // 16-byte vectors along the contiguous dimension of every operand.
+    if (a->K % 8 != 0 && (!a->a_kmajor || !a->b_kmajor))
+        return fail(SFCVIT_EINVAL, "gemm: K=%d must be a multiple of 8 for a k-contiguous operand", a->K);
+    if (a->a_kmajor && a->M % 8 != 0) return fail(SFCVIT_EINVAL, "gemm: M=%d must be a multiple of 8 for k-major A", a->M);
+    if ((a->b_kmajor && a->N % 8 != 0) || a->N % 4 != 0)
+        return fail(SFCVIT_EINVAL, "gemm: N=%d must be a multiple of 4 (8 for k-major B)", a->N);
+    if (a->lda % 8 || a->ldb % 8 || a->ldc % 4) return fail(SFCVIT_EINVAL, "gemm: lda=%d ldb=%d ldc=%d alignment", a->lda, a->ldb, a->ldc);
+    if (!aligned16(a->a) || !aligned16(a->b) || !aligned16(a->c)) return fail(SFCVIT_EINVAL, "gemm: operands must be 16-byte aligned");
+    if (a->residual && (a->ldr % 4 || (reinterpret_cast<uintptr_t>(a->residual) & 7)))
+        return fail(SFCVIT_EINVAL, "gemm: residual alignment");
+    if ((a->aux_in || a->aux_out) && a->ldaux % 4) return fail(SFCVIT_EINVAL, "gemm: ldaux=%d alignment", a->ldaux);
+    if (a->dact != SFCVIT_ACT_NONE && !a->aux_in) return fail(SFCVIT_EINVAL, "gemm: dact needs aux_in");
+    if (a->act < 0 || a->act > 2 || a->dact < 0 || a->dact > 2) return fail(SFCVIT_EINVAL, "gemm: bad act/dact");
+    if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7)) return fail(SFCVIT_EINVAL, "gemm: bias alignment");
+    int splits = a->splitk < 1 ? 1 : a->splitk;
+    const int ktiles = (a->K + BK - 1) / BK;
+    if (splits > ktiles) splits = ktiles;
+    int k_per_split = ((ktiles + splits - 1) / splits) * BK;
+    splits = (a->K + k_per_split - 1) / k_per_split;
+    if (splits > 1) {
+        if (a->bias || a->residual || a->aux_out || a->act || a->dact)
+            return fail(SFCVIT_EINVAL, "gemm: split-K supports no epilogue");
+        if (!a->workspace || a->workspace_bytes < sfcvit_gemm_workspace(a->M, a->N, splits) || !aligned16(a->workspace))
+            return fail(SFCVIT_EINVAL, "gemm: split-K workspace too small (%lld bytes needed)",
+                        (long long)sfcvit_gemm_workspace(a->M, a->N, splits));
+    }
+
+    dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, splits), block(THREADS);
+    if (grid.y > 65535) return fail(SFCVIT_EINVAL, "gemm: M=%d too large", a->M);
+    const size_t lds = 4 * TILE_BYTES;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, s, *a, k_per_split);
+    else if (!a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, s, *a, k_per_split);
+    else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, lds, s, *a, k_per_split);
+    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, s, *a, k_per_split);
+    if (int rc = check_launch("gemm")) return rc;
+    if (splits > 1) {
+        const int64_t nvec = int64_t(a->M) * (a->N / 4);
+        hipLaunchKernelGGL(splitk_reduce, dim3(unsigned((nvec + 255) / 256)), dim3(256), 0, s,
+                           static_cast<const float *>(a->workspace), splits, a->M, a->N, a->c, a->ldc, a->c_is_f32);
+        return check_launch("gemm splitk_reduce");
+    }
+    return SFCVIT_OK;
+}

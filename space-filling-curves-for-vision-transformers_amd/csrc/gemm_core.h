@@ -1,0 +1,104 @@
+// Shared tile machinery of the MFMA GEMM kernels (gemm.hip, patch_embed.hip).
+//
+// Workgroup = 256 threads = 4 waves (2 x 2), tile 128 x 128 x 64; each wave owns a
+// 64 x 64 sub-tile as 4 x 4 accumulator fragments of v_mfma_f32_16x16x32_bf16.
+// The MFMA is issued as D = Bfrag * Afrag, so the accumulator holds C^T:
+//   acc[i][j][r] = C[m][n],  m = wm*64 + i*16 + (lane & 15),  n = wn*64 + j*16 + 4*(lane >> 4) + r
+// i.e. a lane owns 4 consecutive n of one m (8-byte bf16 / 16-byte fp32 epilogue vectors).
+#pragma once
+#include "device_common.h"
+
+namespace sfcvit {
+namespace gemm_core {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int THREADS = 256;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile
+
+struct Stage {
+    u32x4 v[4];
+};
+
+// Global -> registers for one operand tile.  KMAJOR = false: memory is [rows][ld], k
+// contiguous; tile = 128 rows x 64 k.  KMAJOR = true: memory is [K][ld], rows
+// contiguous; tile = 64 k x 128 rows.  Out-of-range vectors are zero.
+template <bool KMAJOR>
+__device__ __forceinline__ void load_tile(Stage &s, const uint16_t *__restrict__ p, int ld, int row0, int nrows,
+                                          int k0, int K, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = tid + THREADS * i;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (!KMAJOR) {
+            const int r = row0 + (v >> 3), k = k0 + ((v & 7) << 3);
+            if (r < nrows && k < K) val = *reinterpret_cast<const u32x4 *>(p + size_t(r) * ld + k);
+        } else {
+            const int k = k0 + (v >> 4), r = row0 + ((v & 15) << 3);
+            if (k < K && r < nrows) val = *reinterpret_cast<const u32x4 *>(p + size_t(k) * ld + r);
+        }
+        s.v[i] = val;
+    }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void store_tile(const Stage &s, char *img, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = tid + THREADS * i;
+        int off;
+        if (!KMAJOR) off = kc_off(v >> 3, v & 7);
+        else off = st_off(v >> 4, (v & 15) << 3);
+        *reinterpret_cast<u32x4 *>(img + off) = s.v[i];
+    }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 frag(const char *img, int row0, int kk, int lane) {
+    if (!KMAJOR) return kc_frag(img, row0, kk, lane);
+    else return st_frag(img, row0, kk, lane);
+}
+
+
+// One 64-deep k-tile of MFMAs from LDS images ia (A tile) and ib (B tile).
+template <bool A_KM, bool B_KM>
+__device__ __forceinline__ void mma_tile(f32x4 (&acc)[4][4], const char *ia, const char *ib, int wm, int wn, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) fa[i] = frag<A_KM>(ia, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j] = frag<B_KM>(ib, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Split-K partial: plain 16-byte stores of the fp32 tile into slab z of the workspace
+// ([splits][M][N] fp32, N % 4 == 0).
+__device__ __forceinline__ void store_partial(const f32x4 (&acc)[4][4], float *slab, int M, int N, int m0, int n0,
+                                              int wm, int wn, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        if (n >= N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (m < M) *reinterpret_cast<f32x4 *>(slab + size_t(m) * N + n) = acc[i][j];
+        }
+    }
+}
+
+}  // namespace gemm_core
+}  // namespace sfcvit

@@ -1,0 +1,283 @@
+// Fused SFC gather + patchify + linear projection for gfx950 (see
+// sfcvit_patch_embed_fwd / _bwd in include/sfcvit.h).
+//
+// The reference does this in three passes over the image (advanced-index gather,
+// reshape copy, GEMM; hilbert_embedding1D.py:36-43) and keeps the gathered
+// [B, N, P*C] tensor for backward.  Here the gather is the A-operand loader of the
+// MFMA GEMM: token rows are assembled in registers from the image through the
+// per-token pixel table and written straight into the LDS tile, so the token
+// matrix never exists in HBM; backward re-gathers it the same way.
+//
+// The contraction index is reordered channel-major (f' = c*P + kk instead of the
+// reference's kk*C + c) so that 8 consecutive features are 8 consecutive curve
+// positions of one channel: one 32-byte read of the pixel table + 8 image reads
+// per LDS vector.  W is permuted to that order once per call into the workspace
+// (D*K bf16, L2-resident); dW is permuted back by the split-K reduction.
+#include "common_host.h"
+#include "gemm_core.h"
+
+namespace sfcvit {
+namespace {
+
+using namespace gemm_core;
+
+struct Geo {
+    const void *x;
+    const int32_t *pix;
+    int B, C, HW, N, P, M, K;   // M = B*N token rows, K = C*P features
+};
+
+// 8 consecutive channel-major features f..f+7 of token row m, as bf16x8 bits.
+template <bool XBF16>
+__device__ __forceinline__ u32x4 gather8(const Geo &g, int m, int f) {
+    const int b = m / g.N, t = m - b * g.N;
+    float v[8];
+    if ((g.P & 7) == 0) {
+        const int c = f / g.P, kk = f - c * g.P;
+        const int32_t *pp = g.pix + size_t(t) * g.P + kk;
+        const u32x4 i0 = *reinterpret_cast<const u32x4 *>(pp), i1 = *reinterpret_cast<const u32x4 *>(pp + 4);
+        const uint32_t idx[8] = {i0[0], i0[1], i0[2], i0[3], i1[0], i1[1], i1[2], i1[3]};
+        const size_t plane = (size_t(b) * g.C + c) * g.HW;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            v[j] = XBF16 ? bf2f(static_cast<const uint16_t *>(g.x)[plane + idx[j]])
+                         : static_cast<const float *>(g.x)[plane + idx[j]];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int ff = f + j;
+            float val = 0.f;
+            if (ff < g.K) {
+                const int c = ff / g.P, kk = ff - c * g.P;
+                const size_t off = (size_t(b) * g.C + c) * g.HW + g.pix[size_t(t) * g.P + kk];
+                val = XBF16 ? bf2f(static_cast<const uint16_t *>(g.x)[off]) : static_cast<const float *>(g.x)[off];
+            }
+            v[j] = val;
+        }
+    }
+    return u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+}
+
+// Token tile for the forward GEMM: 128 token rows x 64 features ("kc" image).
+template <bool XBF16>
+__device__ __forceinline__ void load_tokens_kc(Stage &s, const Geo &g, int m0, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = tid + THREADS * i;
+        const int m = m0 + (v >> 3), f = k0 + ((v & 7) << 3);
+        s.v[i] = (m < g.M && f < g.K) ? gather8<XBF16>(g, m, f) : u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+// Token tile for the weight-gradient GEMM: 64 token rows (contraction) x 128 features ("st" image).
+template <bool XBF16>
+__device__ __forceinline__ void load_tokens_st(Stage &s, const Geo &g, int f0, int m0, int mend, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = tid + THREADS * i;
+        const int m = m0 + (v >> 4), f = f0 + ((v & 15) << 3);
+        s.v[i] = (m < mend && f < g.K) ? gather8<XBF16>(g, m, f) : u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+// W'[d][c*P + kk] = W[d][kk*C + c]
+__global__ __launch_bounds__(256) void permute_w_kernel(const uint16_t *__restrict__ w, uint16_t *__restrict__ wp, int D,
+                                                        int C, int P) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int K = C * P;
+    if (i >= int64_t(D) * K) return;
+    const int d = int(i / K), f = int(i % K);
+    const int c = f / P, kk = f % P;
+    wp[i] = w[size_t(d) * K + kk * C + c];
+}
+
+// y[m, d] = sum_f' tokens'[m, f'] W'[d, f'] + bias[d]
+template <bool XBF16>
+__global__ __launch_bounds__(THREADS, 2) void pe_fwd_kernel(const Geo g, const uint16_t *__restrict__ wp,
+                                                            const uint16_t *__restrict__ bias, uint16_t *__restrict__ y,
+                                                            int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int nk = (g.K + BK - 1) / BK;
+    f32x4 acc[4][4];
+    zero_acc(acc);
+    Stage sa, sb;
+    load_tokens_kc<XBF16>(sa, g, m0, 0, tid);
+    load_tile<false>(sb, wp, g.K, n0, D, 0, g.K, tid);
+    store_tile<false>(sa, smem, tid);
+    store_tile<false>(sb, smem + TILE_BYTES, tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const char *ia = smem + (kt & 1) * 2 * TILE_BYTES;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            load_tokens_kc<XBF16>(sa, g, m0, (kt + 1) * BK, tid);
+            load_tile<false>(sb, wp, g.K, n0, D, (kt + 1) * BK, g.K, tid);
+        }
+        mma_tile<false, false>(acc, ia, ia + TILE_BYTES, wm, wn, lane);
+        if (more) {
+            char *oa = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            store_tile<false>(sa, oa, tid);
+            store_tile<false>(sb, oa + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        if (n >= D) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const u32x2 b2 = *reinterpret_cast<const u32x2 *>(bias + n);
+            bv[0] = bf2f(uint16_t(b2[0])); bv[1] = bf2f(uint16_t(b2[0] >> 16));
+            bv[2] = bf2f(uint16_t(b2[1])); bv[3] = bf2f(uint16_t(b2[1] >> 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (m >= g.M) continue;
+            u32x2 o = {pack2bf(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]), pack2bf(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3])};
+            *reinterpret_cast<u32x2 *>(y + size_t(m) * D + n) = o;
+        }
+    }
+}
+
+// slab[z][d, f'] = sum_{m in split z} dY[m, d] tokens'[m, f']
+template <bool XBF16>
+__global__ __launch_bounds__(THREADS, 2) void pe_bwd_kernel(const Geo g, const uint16_t *__restrict__ dy,
+                                                            float *__restrict__ slabs, int D, int m_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int d0 = blockIdx.y * BM, f0 = blockIdx.x * BN;
+    const int mbeg = blockIdx.z * m_per_split, mend = min(g.M, mbeg + m_per_split);
+    const int nk = (mend - mbeg + BK - 1) / BK;
+    f32x4 acc[4][4];
+    zero_acc(acc);
+    Stage sa, sb;
+    load_tile<true>(sa, dy, D, d0, D, mbeg, mend, tid);
+    load_tokens_st<XBF16>(sb, g, f0, mbeg, mend, tid);
+    store_tile<true>(sa, smem, tid);
+    store_tile<true>(sb, smem + TILE_BYTES, tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const char *ia = smem + (kt & 1) * 2 * TILE_BYTES;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            load_tile<true>(sa, dy, D, d0, D, mbeg + (kt + 1) * BK, mend, tid);
+            load_tokens_st<XBF16>(sb, g, f0, mbeg + (kt + 1) * BK, mend, tid);
+        }
+        mma_tile<true, true>(acc, ia, ia + TILE_BYTES, wm, wn, lane);
+        if (more) {
+            char *oa = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            store_tile<true>(sa, oa, tid);
+            store_tile<true>(sb, oa + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+    store_partial(acc, slabs + size_t(blockIdx.z) * D * g.K, D, g.K, d0, f0, wm, wn, lane);
+}
+
+// dW[d][kk*C + c] = sum_z slab[z][d][c*P + kk]
+__global__ __launch_bounds__(256) void pe_bwd_reduce(const float *__restrict__ slabs, int splits, float *__restrict__ dw,
+                                                     int D, int C, int P) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int K = C * P;
+    if (i >= int64_t(D) * K) return;
+    const int d = int(i / K), f = int(i % K);
+    const int c = f / P, kk = f % P;
+    float s = 0.f;
+    for (int z = 0; z < splits; z++) s += slabs[(size_t(z) * D + d) * K + f];
+    dw[size_t(d) * K + kk * C + c] = s;
+}
+
+int bwd_splits(int M, int D, int K) {
+    const int tiles = ((D + BM - 1) / BM) * ((K + BN - 1) / BN);
+    int splits = (1024 + tiles - 1) / tiles;
+    const int ktiles = (M + BK - 1) / BK;
+    if (splits > ktiles) splits = ktiles;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+int check_args(const sfcvit_patch_embed_args *a, const char *what) {
+    if (!a || !a->x || !a->pix || !a->y) return fail(SFCVIT_EINVAL, "%s: null pointer", what);
+    if (a->B <= 0 || a->C <= 0 || a->HW <= 0 || a->N <= 0 || a->P <= 0 || a->D <= 0)
+        return fail(SFCVIT_EINVAL, "%s: non-positive dimension", what);
+    if (int64_t(a->N) * a->P != a->HW) return fail(SFCVIT_EINVAL, "%s: N*P=%lld must equal H*W=%d", what, (long long)a->N * a->P, a->HW);
+    if ((int64_t(a->C) * a->P) % 8 != 0) return fail(SFCVIT_EINVAL, "%s: C*P=%d must be a multiple of 8", what, a->C * a->P);
+    if (a->D % 8 != 0) return fail(SFCVIT_EINVAL, "%s: D=%d must be a multiple of 8", what, a->D);
+    if (int64_t(a->B) * a->N > 0x7fffffff / 2) return fail(SFCVIT_EINVAL, "%s: B*N too large", what);
+    if (!aligned16(a->x) || !aligned16(a->pix) || !aligned16(a->y)) return fail(SFCVIT_EINVAL, "%s: alignment", what);
+    return SFCVIT_OK;
+}
+
+Geo make_geo(const sfcvit_patch_embed_args *a) {
+    return Geo{a->x, a->pix, a->B, a->C, a->HW, a->N, a->P, a->B * a->N, a->C * a->P};
+}
+
+}  // namespace
+}  // namespace sfcvit
+
+using namespace sfcvit;
+
+extern "C" int64_t sfcvit_patch_embed_workspace(int B, int C, int N, int P, int D, int bwd) {
+    if (B <= 0 || C <= 0 || N <= 0 || P <= 0 || D <= 0) return 0;
+    const int64_t K = int64_t(C) * P;
+    if (!bwd) return ((int64_t(D) * K * 2 + 15) / 16) * 16;
+    return int64_t(bwd_splits(B * N, D, int(K))) * D * K * int64_t(sizeof(float));
+}
+
+extern "C" int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *stream) {
+    if (int rc = check_args(a, "patch_embed_fwd")) return rc;
+    if (!a->w) return fail(SFCVIT_EINVAL, "patch_embed_fwd: null weight");
+    const int64_t need = sfcvit_patch_embed_workspace(a->B, a->C, a->N, a->P, a->D, 0);
+    if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace))
+        return fail(SFCVIT_EINVAL, "patch_embed_fwd: workspace of %lld bytes needed", (long long)need);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Geo g = make_geo(a);
+    uint16_t *wp = static_cast<uint16_t *>(a->workspace);
+    const int64_t nw = int64_t(a->D) * g.K;
+    hipLaunchKernelGGL(permute_w_kernel, dim3(unsigned((nw + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const uint16_t *>(a->w), wp, a->D, a->C, a->P);
+    if (int rc = check_launch("patch_embed_fwd permute")) return rc;
+    dim3 grid((a->D + BN - 1) / BN, (g.M + BM - 1) / BM), block(THREADS);
+    const size_t lds = 4 * TILE_BYTES;
+    if (a->x_is_bf16)
+        hipLaunchKernelGGL(pe_fwd_kernel<true>, grid, block, lds, s, g, wp, static_cast<const uint16_t *>(a->bias),
+                           static_cast<uint16_t *>(a->y), a->D);
+    else
+        hipLaunchKernelGGL(pe_fwd_kernel<false>, grid, block, lds, s, g, wp, static_cast<const uint16_t *>(a->bias),
+                           static_cast<uint16_t *>(a->y), a->D);
+    return check_launch("patch_embed_fwd");
+}
+
+extern "C" int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *stream) {
+    if (int rc = check_args(a, "patch_embed_bwd")) return rc;
+    if (!a->dw) return fail(SFCVIT_EINVAL, "patch_embed_bwd: null dw");
+    const int64_t need = sfcvit_patch_embed_workspace(a->B, a->C, a->N, a->P, a->D, 1);
+    if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace))
+        return fail(SFCVIT_EINVAL, "patch_embed_bwd: workspace of %lld bytes needed", (long long)need);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Geo g = make_geo(a);
+    const int splits = bwd_splits(g.M, a->D, g.K);
+    const int ktiles = (g.M + BK - 1) / BK;
+    const int m_per_split = ((ktiles + splits - 1) / splits) * BK;
+    const int zs = (g.M + m_per_split - 1) / m_per_split;
+    float *slabs = static_cast<float *>(a->workspace);
+    dim3 grid((g.K + BN - 1) / BN, (a->D + BM - 1) / BM, zs), block(THREADS);
+    const size_t lds = 4 * TILE_BYTES;
+    if (a->x_is_bf16)
+        hipLaunchKernelGGL(pe_bwd_kernel<true>, grid, block, lds, s, g, static_cast<const uint16_t *>(a->y), slabs, a->D, m_per_split);
+    else
+        hipLaunchKernelGGL(pe_bwd_kernel<false>, grid, block, lds, s, g, static_cast<const uint16_t *>(a->y), slabs, a->D, m_per_split);
+    if (int rc = check_launch("patch_embed_bwd")) return rc;
+    const int64_t nw = int64_t(a->D) * g.K;
+    hipLaunchKernelGGL(pe_bwd_reduce, dim3(unsigned((nw + 255) / 256)), dim3(256), 0, s, slabs, zs,
+                       static_cast<float *>(a->dw), a->D, a->C, a->P);
+    if (int rc = check_launch("patch_embed_bwd reduce")) return rc;
+    if (a->dbias) return sfcvit_colsum(a->y, g.M, a->D, a->D, static_cast<float *>(a->dbias), stream);
+    return SFCVIT_OK;
+}

@@ -1,0 +1,446 @@
+// HBM-bound row-wise kernels for gfx950: LayerNorm forward/backward, column sums
+// (bias gradients), GELU, soft-target cross-entropy, sum of squares and the fused
+// clip + AdamW step.  One 64-lane wave owns one row; every global access is a
+// 16-byte vector (8 bf16 or 4 fp32) and reductions are wave butterflies.
+#include "common_host.h"
+#include "device_common.h"
+
+namespace sfcvit {
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / 64;
+
+__device__ __forceinline__ void unpack8(const u32x4 &v, float *f) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f[2 * i] = bf2f(uint16_t(v[i]));
+        f[2 * i + 1] = bf2f(uint16_t(v[i] >> 16));
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float *f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm forward.  VPL = 16-byte vectors per lane (D <= VPL * 512).
+// ---------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ gamma,
+                                                         const uint16_t *__restrict__ beta, uint16_t *__restrict__ y,
+                                                         float *__restrict__ mean, float *__restrict__ rstd, int M,
+                                                         int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nvec = D >> 3;
+    float v[VPL][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            unpack8(*reinterpret_cast<const u32x4 *>(x + size_t(row) * D + c * 8), v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s += v[i][j];
+        }
+    }
+    const float mu = wave_sum(s) / float(D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++)
+        if (lane + 64 * i < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float d = v[i][j] - mu;
+                q += d * d;
+            }
+        }
+    const float rs = rsqrtf(wave_sum(q) / float(D) + eps);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            float g[8], b[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4 *>(gamma + c * 8), g);
+            unpack8(*reinterpret_cast<const u32x4 *>(beta + c * 8), b);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+            *reinterpret_cast<u32x4 *>(y + size_t(row) * D + c * 8) = pack8(o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm backward.  Each wave walks rows with a grid stride, keeps its lanes'
+// columns of dgamma / dbeta in registers, and the block writes one partial row
+// [2][D] to the workspace; ln_bwd_reduce sums the partials.
+// ---------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                         const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                         const uint16_t *__restrict__ gamma,
+                                                         const uint16_t *__restrict__ dx_add, uint16_t *__restrict__ dx,
+                                                         float *__restrict__ partial, int M, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [WAVES][2][D] fp32
+    float *red = reinterpret_cast<float *>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = D >> 3;
+    float g[VPL][8], dg[VPL][8], db[VPL][8];
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < nvec) unpack8(*reinterpret_cast<const u32x4 *>(gamma + c * 8), g[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) dg[i][j] = db[i][j] = 0.f;
+    }
+    for (int row = blockIdx.x * WAVES + wave; row < M; row += gridDim.x * WAVES) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[VPL][8], gy[VPL][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                float xv[8], dv[8];
+                unpack8(*reinterpret_cast<const u32x4 *>(x + size_t(row) * D + c * 8), xv);
+                unpack8(*reinterpret_cast<const u32x4 *>(dy + size_t(row) * D + c * 8), dv);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    xh[i][j] = (xv[j] - mu) * rs;
+                    gy[i][j] = dv[j] * g[i][j];
+                    s1 += gy[i][j];
+                    s2 += gy[i][j] * xh[i][j];
+                    dg[i][j] += dv[j] * xh[i][j];
+                    db[i][j] += dv[j];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / float(D), c2 = wave_sum(s2) / float(D);
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = rs * (gy[i][j] - c1 - xh[i][j] * c2);
+                if (dx_add) {
+                    float a[8];
+                    unpack8(*reinterpret_cast<const u32x4 *>(dx_add + size_t(row) * D + c * 8), a);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) o[j] += a[j];
+                }
+                *reinterpret_cast<u32x4 *>(dx + size_t(row) * D + c * 8) = pack8(o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                red[(wave * 2 + 0) * D + c * 8 + j] = dg[i][j];
+                red[(wave * 2 + 1) * D + c * 8 + j] = db[i][j];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) s += red[w * 2 * D + c];
+        partial[size_t(blockIdx.x) * 2 * D + c] = s;
+    }
+}
+
+__global__ void ln_bwd_reduce(const float *__restrict__ partial, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                              int nblocks, int D) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * D) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; b++) s += partial[size_t(b) * 2 * D + c];
+    if (c < D) dgamma[c] = s;
+    else dbeta[c - D] = s;
+}
+
+int ln_bwd_blocks(int M) {
+    const int want = (M + WAVES - 1) / WAVES;
+    return want < 1024 ? want : 1024;
+}
+
+// ---------------------------------------------------------------------------
+// Column sums of a bf16 [M, ld] matrix (bias gradients).
+// Thread (cv, rl) owns 8 columns and every 8th row of the block's row range.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void colsum_kernel(const uint16_t *__restrict__ x, int M, int N, int ld,
+                                                         int rows_per_block, float *__restrict__ out) {
+    __shared__ float red[8][256];
+    const int cv = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 256 + cv * 8;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4 *>(x + size_t(r) * ld + col), v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) red[rl][cv * 8 + j] = s[j];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; r++) t += red[r][threadIdx.x];
+        atomicAdd(out + c, t);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GELU (erf form)
+// ---------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(THREADS) void gelu_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                       uint16_t *__restrict__ out, int64_t nvec) {
+    for (int64_t i = blockIdx.x * int64_t(THREADS) + threadIdx.x; i < nvec; i += int64_t(gridDim.x) * THREADS) {
+        float xv[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4 *>(x + i * 8), xv);
+        if (BWD) {
+            float dv[8];
+            unpack8(*reinterpret_cast<const u32x4 *>(dy + i * 8), dv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = dv[j] * gelu_erf_grad(xv[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = gelu_erf(xv[j]);
+        }
+        *reinterpret_cast<u32x4 *>(out + i * 8) = pack8(o);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Soft-target cross entropy: one wave per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void soft_ce_kernel(const uint16_t *__restrict__ logits,
+                                                          const float *__restrict__ targets,
+                                                          float *__restrict__ loss_rows, uint16_t *__restrict__ dlogits,
+                                                          int B, int C, int ld, float gscale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const uint16_t *l = logits + size_t(row) * ld;
+    const float *t = targets + size_t(row) * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, bf2f(l[c]));
+    mx = wave_max(mx);
+    float se = 0.f, st = 0.f, stl = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float z = bf2f(l[c]);
+        se += __expf(z - mx);
+        st += t[c];
+        stl += t[c] * z;
+    }
+    se = wave_sum(se);
+    st = wave_sum(st);
+    stl = wave_sum(stl);
+    const float lse = mx + __logf(se);
+    if (lane == 0) loss_rows[row] = lse * st - stl;   // -sum t*(z - lse)
+    if (dlogits) {
+        uint16_t *d = dlogits + size_t(row) * ld;
+        for (int c = lane; c < ld; c += 64) {
+            float gr = 0.f;
+            if (c < C) gr = (__expf(bf2f(l[c]) - lse) * st - t[c]) * gscale;
+            d[c] = f2bf(gr);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sum of squares (gradient norm) and fused clip + AdamW
+// ---------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(THREADS) void sumsq_kernel(const void *__restrict__ g, int64_t n, float *__restrict__ out) {
+    __shared__ float red[WAVES];
+    float s = 0.f;
+    const int64_t nvec = n >> 3;
+    for (int64_t i = blockIdx.x * int64_t(THREADS) + threadIdx.x; i < nvec; i += int64_t(gridDim.x) * THREADS) {
+        float v[8];
+        if (F32) {
+            const f32x4 a = reinterpret_cast<const f32x4 *>(g)[2 * i], b = reinterpret_cast<const f32x4 *>(g)[2 * i + 1];
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
+            unpack8(reinterpret_cast<const u32x4 *>(g)[i], v);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += v[j] * v[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < int(n & 7)) {   // tail (< 8 elements)
+        const int64_t i = (nvec << 3) + threadIdx.x;
+        const float v = F32 ? static_cast<const float *>(g)[i] : bf2f(static_cast<const uint16_t *>(g)[i]);
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) t += red[w];
+        atomicAdd(out, t);
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void adamw_kernel(const sfcvit_adamw_args a, float bc1, float bc2) {
+    float clip = 1.f;
+    if (a.sumsq) {
+        const float norm = sqrtf(*a.sumsq);
+        clip = fminf(1.f, a.max_norm / (norm + 1e-6f));
+    }
+    uint16_t *p = static_cast<uint16_t *>(a.param);
+    const uint16_t *g = static_cast<const uint16_t *>(a.grad);
+    for (int64_t i = blockIdx.x * int64_t(THREADS) + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * THREADS) {
+        const float gr = bf2f(g[i]) * clip;
+        float w = a.master[i];
+        float m = a.m[i], v = a.v[i];
+        w *= 1.f - a.lr * a.weight_decay;
+        m = a.beta1 * m + (1.f - a.beta1) * gr;
+        v = a.beta2 * v + (1.f - a.beta2) * gr * gr;
+        const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
+        w -= (a.lr / bc1) * (m / denom);
+        a.master[i] = w;
+        a.m[i] = m;
+        a.v[i] = v;
+        p[i] = f2bf(w);
+    }
+}
+
+int grid_for(int64_t work_items) {
+    int64_t b = (work_items + THREADS - 1) / THREADS;
+    if (b < 1) b = 1;
+    return int(b > 2048 ? 2048 : b);
+}
+
+}  // namespace
+}  // namespace sfcvit
+
+using namespace sfcvit;
+
+extern "C" int sfcvit_layernorm_fwd(const void *x, const void *gamma, const void *beta, void *y, float *mean,
+                                    float *rstd, int M, int D, float eps, void *stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return fail(SFCVIT_EINVAL, "layernorm_fwd: null pointer");
+    if (M <= 0 || D <= 0 || D % 8 || D > 4096) return fail(SFCVIT_EINVAL, "layernorm_fwd: M=%d D=%d (D %% 8 == 0, D <= 4096)", M, D);
+    if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta)) return fail(SFCVIT_EINVAL, "layernorm_fwd: alignment");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((M + WAVES - 1) / WAVES), block(THREADS);
+    const auto *xp = static_cast<const uint16_t *>(x);
+    const auto *gp = static_cast<const uint16_t *>(gamma);
+    const auto *bp = static_cast<const uint16_t *>(beta);
+    auto *yp = static_cast<uint16_t *>(y);
+    if (D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, xp, gp, bp, yp, mean, rstd, M, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, xp, gp, bp, yp, mean, rstd, M, D, eps);
+    else if (D <= 2048) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, xp, gp, bp, yp, mean, rstd, M, D, eps);
+    else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, s, xp, gp, bp, yp, mean, rstd, M, D, eps);
+    return check_launch("layernorm_fwd");
+}
+
+extern "C" int64_t sfcvit_layernorm_bwd_ws(int M, int D) {
+    if (M <= 0 || D <= 0) return 0;
+    return int64_t(ln_bwd_blocks(M)) * 2 * D * int64_t(sizeof(float));
+}
+
+extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const float *rstd,
+                                    const void *gamma, const void *dx_add, void *dx, float *dgamma, float *dbeta,
+                                    int M, int D, void *ws, void *stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !ws)
+        return fail(SFCVIT_EINVAL, "layernorm_bwd: null pointer");
+    if (M <= 0 || D <= 0 || D % 8 || D > 2048) return fail(SFCVIT_EINVAL, "layernorm_bwd: M=%d D=%d (D %% 8 == 0, D <= 2048)", M, D);
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma) || (dx_add && !aligned16(dx_add)))
+        return fail(SFCVIT_EINVAL, "layernorm_bwd: alignment");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = ln_bwd_blocks(M);
+    dim3 grid(nb), block(THREADS);
+    const size_t lds = size_t(WAVES) * 2 * D * sizeof(float);
+    const auto *dyp = static_cast<const uint16_t *>(dy);
+    const auto *xp = static_cast<const uint16_t *>(x);
+    const auto *gp = static_cast<const uint16_t *>(gamma);
+    const auto *ap = static_cast<const uint16_t *>(dx_add);
+    auto *dxp = static_cast<uint16_t *>(dx);
+    float *part = static_cast<float *>(ws);
+    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, part, M, D);
+    else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, part, M, D);
+    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, part, M, D);
+    if (int rc = check_launch("layernorm_bwd")) return rc;
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 255) / 256), dim3(256), 0, s, part, dgamma, dbeta, nb, D);
+    return check_launch("layernorm_bwd_reduce");
+}
+
+extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *stream) {
+    if (!x || !out) return fail(SFCVIT_EINVAL, "colsum: null pointer");
+    if (M <= 0 || N <= 0 || N % 8 || ld % 8 || ld < N) return fail(SFCVIT_EINVAL, "colsum: M=%d N=%d ld=%d (N, ld %% 8 == 0)", M, N, ld);
+    if (!aligned16(x)) return fail(SFCVIT_EINVAL, "colsum: alignment");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out, 0, size_t(N) * sizeof(float), s) != hipSuccess) return check_launch("colsum memset");
+    const int col_blocks = (N + 255) / 256;
+    int row_blocks = 2048 / col_blocks;
+    if (row_blocks < 1) row_blocks = 1;
+    int rpb = (M + row_blocks - 1) / row_blocks;
+    rpb = ((rpb + 7) / 8) * 8;
+    row_blocks = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(THREADS), 0, s,
+                       static_cast<const uint16_t *>(x), M, N, ld, rpb, out);
+    return check_launch("colsum");
+}
+
+extern "C" int sfcvit_gelu_fwd(const void *x, void *y, int64_t n, void *stream) {
+    if (!x || !y || n <= 0 || n % 8) return fail(SFCVIT_EINVAL, "gelu_fwd: n=%lld must be a positive multiple of 8", (long long)n);
+    hipLaunchKernelGGL(gelu_kernel<false>, dim3(grid_for(n / 8)), dim3(THREADS), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(nullptr), static_cast<const uint16_t *>(x), static_cast<uint16_t *>(y), n / 8);
+    return check_launch("gelu_fwd");
+}
+
+extern "C" int sfcvit_gelu_bwd(const void *dy, const void *x, void *dx, int64_t n, void *stream) {
+    if (!dy || !x || !dx || n <= 0 || n % 8) return fail(SFCVIT_EINVAL, "gelu_bwd: n=%lld must be a positive multiple of 8", (long long)n);
+    hipLaunchKernelGGL(gelu_kernel<true>, dim3(grid_for(n / 8)), dim3(THREADS), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(dy), static_cast<const uint16_t *>(x), static_cast<uint16_t *>(dx), n / 8);
+    return check_launch("gelu_bwd");
+}
+
+extern "C" int sfcvit_soft_ce(const void *logits, const float *targets, float *loss_rows, void *dlogits, int B, int C,
+                              int ld, float gscale, void *stream) {
+    if (!logits || !targets || !loss_rows) return fail(SFCVIT_EINVAL, "soft_ce: null pointer");
+    if (B <= 0 || C <= 0 || ld < C) return fail(SFCVIT_EINVAL, "soft_ce: B=%d C=%d ld=%d", B, C, ld);
+    hipLaunchKernelGGL(soft_ce_kernel, dim3((B + WAVES - 1) / WAVES), dim3(THREADS), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(logits), targets, loss_rows, static_cast<uint16_t *>(dlogits), B, C, ld, gscale);
+    return check_launch("soft_ce");
+}
+
+extern "C" int sfcvit_sumsq_accum(const void *g, int64_t n, int is_f32, float *out, void *stream) {
+    if (!g || !out || n <= 0) return fail(SFCVIT_EINVAL, "sumsq: bad argument");
+    if (!aligned16(g)) return fail(SFCVIT_EINVAL, "sumsq: alignment");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for((n + 7) / 8);
+    if (is_f32) hipLaunchKernelGGL(sumsq_kernel<true>, dim3(grid), dim3(THREADS), 0, s, g, n, out);
+    else hipLaunchKernelGGL(sumsq_kernel<false>, dim3(grid), dim3(THREADS), 0, s, g, n, out);
+    return check_launch("sumsq");
+}
+
+extern "C" int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream) {
+    if (!a || !a->param || !a->master || !a->grad || !a->m || !a->v) return fail(SFCVIT_EINVAL, "adamw: null pointer");
+    if (a->n <= 0 || a->step < 1) return fail(SFCVIT_EINVAL, "adamw: n=%lld step=%d", (long long)a->n, a->step);
+    const float bc1 = 1.f - powf(a->beta1, float(a->step));
+    const float bc2 = 1.f - powf(a->beta2, float(a->step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n)), dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a, bc1, bc2);
+    return check_launch("adamw");
+}

@@ -1,0 +1,263 @@
+"""Thin, allocation-only wrappers over the C ABI (include/sfcvit.h).
+
+Every function here takes torch CUDA tensors, checks dtype / contiguity, allocates
+outputs with torch's caching allocator and launches the HIP kernels on torch's
+current stream.  There is no CPU path: a CPU tensor raises.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+_BF16 = torch.bfloat16
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need(t, dtype, name, dims=None):
+    if not t.is_cuda:
+        raise _lib.SfcvitError(f"{name}: the HIP path needs a CUDA (ROCm) tensor, got device {t.device}; "
+                               "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if dims is not None and t.dim() != dims:
+        raise ValueError(f"{name}: expected {dims}-D, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _rows2d(t, dtype, name):
+    """2-D, unit inner stride, arbitrary row stride (views of packed buffers are fine)."""
+    if not t.is_cuda:
+        raise _lib.SfcvitError(f"{name}: the HIP path needs a CUDA (ROCm) tensor; there is no CPU fallback")
+    if t.dtype != dtype or t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected 2-D {dtype} with unit inner stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+    return t
+
+
+# ----------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------
+def auto_splitk(M, N, K):
+    """Split K when the output has too few 128x128 tiles to fill 256 CUs (2 WG/CU)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 256 or K < 2048:
+        return 1
+    return max(1, min((768 + tiles - 1) // tiles, K // 512))
+
+
+def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, residual=None,
+         aux_in=None, dact=ACT_NONE, want_aux=False, out_f32=False, splitk=None):
+    """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  a: [M,K] (or [K,M] if a_kmajor),
+    b: [N,K] (or [K,N] if b_kmajor), bf16.  Returns C (and the pre-activation if want_aux)."""
+    _rows2d(a, _BF16, "gemm a")
+    _rows2d(b, _BF16, "gemm b")
+    M, K = (a.shape[1], a.shape[0]) if a_kmajor else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[1], b.shape[0]) if b_kmajor else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise ValueError(f"gemm: contraction mismatch {K} vs {Kb}")
+    c = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else _BF16)
+    aux = torch.empty((M, N), device=a.device, dtype=_BF16) if want_aux else None
+    args = _lib.GemmArgs()
+    args.a, args.b, args.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    args.bias = _need(bias, _BF16, "gemm bias", 1).data_ptr() if bias is not None else None
+    args.M, args.N, args.K = M, N, K
+    args.lda, args.ldb, args.ldc = a.stride(0), b.stride(0), N
+    if residual is not None:
+        _rows2d(residual, _BF16, "gemm residual")
+        args.residual, args.ldr = residual.data_ptr(), residual.stride(0)
+    ldaux = N
+    if aux_in is not None:
+        _rows2d(aux_in, _BF16, "gemm aux_in")
+        args.aux_in, ldaux = aux_in.data_ptr(), aux_in.stride(0)
+    if aux is not None:
+        args.aux_out = aux.data_ptr()
+    args.ldaux = ldaux
+    args.a_kmajor, args.b_kmajor = int(a_kmajor), int(b_kmajor)
+    args.act, args.dact, args.c_is_f32 = act, dact, int(out_f32)
+    plain = bias is None and residual is None and aux_in is None and not want_aux and act == 0 and dact == 0
+    if splitk is None:
+        splitk = auto_splitk(M, N, K) if plain else 1
+    ws = None
+    if splitk > 1:
+        nbytes = lib.sfcvit_gemm_workspace(M, N, splitk)
+        ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), nbytes
+    args.splitk = splitk
+    check(lib.sfcvit_gemm(ctypes.byref(args), _stream()), "sfcvit_gemm")
+    return (c, aux) if want_aux else c
+
+
+def colsum(x):
+    _rows2d(x, _BF16, "colsum x")
+    out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+    check(lib.sfcvit_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(out), _stream()), "sfcvit_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# LayerNorm
+# ----------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    _need(x, _BF16, "layernorm x", 2)
+    M, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    check(lib.sfcvit_layernorm_fwd(_p(x), _p(_need(gamma, _BF16, "gamma", 1)), _p(_need(beta, _BF16, "beta", 1)),
+                                   _p(y), _p(mean), _p(rstd), M, D, eps, _stream()), "sfcvit_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None):
+    _need(dy, _BF16, "layernorm dy", 2)
+    _need(x, _BF16, "layernorm x", 2)
+    M, D = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(D, device=x.device, dtype=torch.float32)
+    db = torch.empty(D, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.sfcvit_layernorm_bwd_ws(M, D), device=x.device, dtype=torch.uint8)
+    if dx_add is not None:
+        _need(dx_add, _BF16, "layernorm dx_add", 2)
+    check(lib.sfcvit_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_add), _p(dx), _p(dg), _p(db),
+                                   M, D, _p(ws), _stream()), "sfcvit_layernorm_bwd")
+    return dx, dg, db
+
+
+# ----------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------
+def attention_fwd(qkv, n_heads):
+    """qkv [B, N, 3*D] bf16 -> out [B, N, D] bf16, lse [B, H, N] fp32."""
+    _need(qkv, _BF16, "attention qkv", 3)
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // n_heads
+    out = torch.empty((B, N, D), device=qkv.device, dtype=_BF16)
+    lse = torch.empty((B, n_heads, N), device=qkv.device, dtype=torch.float32)
+    a = _lib.AttnArgs()
+    a.qkv, a.out, a.lse = qkv.data_ptr(), out.data_ptr(), lse.data_ptr()
+    a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
+    check(lib.sfcvit_attention_fwd(ctypes.byref(a), _stream()), "sfcvit_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, lse, dout, n_heads):
+    _need(dout, _BF16, "attention dout", 3)
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // n_heads
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, n_heads, N), device=qkv.device, dtype=torch.float32)
+    a = _lib.AttnArgs()
+    a.qkv, a.out, a.lse, a.dout = qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr()
+    a.dqkv, a.delta = dqkv.data_ptr(), delta.data_ptr()
+    a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
+    check(lib.sfcvit_attention_bwd(ctypes.byref(a), _stream()), "sfcvit_attention_bwd")
+    return dqkv
+
+
+# ----------------------------------------------------------------------------
+# tokenizer
+# ----------------------------------------------------------------------------
+def _pe_args(x, pix, n_tokens, P, D):
+    if not x.is_cuda:
+        raise _lib.SfcvitError("patch_embed: the HIP path needs a CUDA (ROCm) tensor; there is no CPU fallback")
+    if x.dtype not in (torch.float32, _BF16) or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError(f"patch_embed x: expected contiguous [B,C,H,W] fp32/bf16, got {x.dtype} {tuple(x.shape)}")
+    _need(pix, torch.int32, "patch_embed pix", 2)
+    B, C, H, W = x.shape
+    a = _lib.PatchEmbedArgs()
+    a.x, a.pix = x.data_ptr(), pix.data_ptr()
+    a.B, a.C, a.HW, a.N, a.P, a.D = B, C, H * W, n_tokens, P, D
+    a.x_is_bf16 = int(x.dtype == _BF16)
+    return a
+
+
+def patch_embed_fwd(x, pix, w, bias):
+    """x [B,C,H,W] fp32/bf16, pix [N,P] int32 (device), w [D, P*C] bf16 -> [B, N, D] bf16."""
+    N, P = pix.shape
+    D = w.shape[0]
+    _need(w, _BF16, "patch_embed w", 2)
+    a = _pe_args(x, pix, N, P, D)
+    y = torch.empty((x.shape[0], N, D), device=x.device, dtype=_BF16)
+    nbytes = lib.sfcvit_patch_embed_workspace(a.B, a.C, N, P, D, 0)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    a.w, a.y, a.workspace, a.workspace_bytes = w.data_ptr(), y.data_ptr(), ws.data_ptr(), nbytes
+    a.bias = _need(bias, _BF16, "patch_embed bias", 1).data_ptr() if bias is not None else None
+    check(lib.sfcvit_patch_embed_fwd(ctypes.byref(a), _stream()), "sfcvit_patch_embed_fwd")
+    return y
+
+
+def patch_embed_bwd(x, pix, dy, D, want_bias=True):
+    """-> dW fp32 [D, P*C], dbias fp32 [D]."""
+    N, P = pix.shape
+    _need(dy, _BF16, "patch_embed dy", 3)
+    a = _pe_args(x, pix, N, P, D)
+    dw = torch.empty((D, P * a.C), device=x.device, dtype=torch.float32)
+    db = torch.empty(D, device=x.device, dtype=torch.float32) if want_bias else None
+    nbytes = lib.sfcvit_patch_embed_workspace(a.B, a.C, N, P, D, 1)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    a.y, a.dw, a.dbias = dy.data_ptr(), dw.data_ptr(), (db.data_ptr() if want_bias else None)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.sfcvit_patch_embed_bwd(ctypes.byref(a), _stream()), "sfcvit_patch_embed_bwd")
+    return dw, db
+
+
+# ----------------------------------------------------------------------------
+# elementwise / loss / optimizer
+# ----------------------------------------------------------------------------
+def gelu_fwd(x):
+    _need(x, _BF16, "gelu x")
+    y = torch.empty_like(x)
+    check(lib.sfcvit_gelu_fwd(_p(x), _p(y), x.numel(), _stream()), "sfcvit_gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy, x):
+    _need(x, _BF16, "gelu x")
+    _need(dy, _BF16, "gelu dy")
+    dx = torch.empty_like(x)
+    check(lib.sfcvit_gelu_bwd(_p(dy), _p(x), _p(dx), x.numel(), _stream()), "sfcvit_gelu_bwd")
+    return dx
+
+
+def soft_ce(logits, targets, n_classes, gscale):
+    """logits bf16 [B, ld] (first n_classes columns are classes), targets fp32 [B, C].
+    -> loss_rows fp32 [B], dlogits bf16 [B, ld] (already multiplied by gscale)."""
+    _need(logits, _BF16, "soft_ce logits", 2)
+    _need(targets, torch.float32, "soft_ce targets", 2)
+    B, ld = logits.shape
+    loss_rows = torch.empty(B, device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty_like(logits)
+    check(lib.sfcvit_soft_ce(_p(logits), _p(targets), _p(loss_rows), _p(dlogits), B, n_classes, ld, gscale, _stream()),
+          "sfcvit_soft_ce")
+    return loss_rows, dlogits
+
+
+def sumsq_accum(g, out):
+    is_f32 = g.dtype == torch.float32
+    if not is_f32:
+        _need(g, _BF16, "sumsq g")
+    check(lib.sfcvit_sumsq_accum(_p(g), g.numel(), int(is_f32), _p(out), _stream()), "sfcvit_sumsq_accum")
+
+
+def adamw_step(param, master, grad, m, v, sumsq, *, lr, beta1, beta2, eps, weight_decay, max_norm, step):
+    a = _lib.AdamWArgs()
+    a.param, a.master, a.grad, a.m, a.v = (param.data_ptr(), master.data_ptr(), grad.data_ptr(),
+                                           m.data_ptr(), v.data_ptr())
+    a.sumsq = sumsq.data_ptr() if sumsq is not None else None
+    a.n = param.numel()
+    a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.max_norm, a.step = lr, beta1, beta2, eps, weight_decay, max_norm, step
+    check(lib.sfcvit_adamw_step(ctypes.byref(a), _stream()), "sfcvit_adamw_step")

@@ -1,0 +1,223 @@
+"""HIP kernels through the C ABI against fp32 torch math on the same bf16-rounded inputs.
+
+Tolerances: outputs are bf16 (8 significant bits) of fp32-accumulated sums, so the
+bar is |err| <= 2^-7 * |ref| + a small absolute term scaled to the output's rms."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sfcvit import ops as o
+    return o
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def close(got, ref, rel=1.0 / 128, abs_scale=1.0 / 64):
+    got, ref = got.float(), ref.float()
+    tol = rel * ref.abs() + abs_scale * ref.pow(2).mean().sqrt().clamp_min(1e-6)
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())}/{bad.numel()} off, max err {float((got - ref).abs().max())}, ref rms {float(ref.pow(2).mean().sqrt())}"
+
+
+def gelu_ref(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+@pytest.mark.parametrize("akm", [False, True])
+@pytest.mark.parametrize("bkm", [False, True])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 328), (1024, 576, 192), (40, 16, 1000)])
+def test_gemm_layouts(ops, akm, bkm, M, N, K):
+    if akm and M % 8:
+        pytest.skip("k-major A needs M % 8 == 0")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    b = bf(torch.randn(N, K, device="cuda", generator=g))
+    ref = a.float() @ b.float().t()
+    am = a.t().contiguous() if akm else a
+    bm = b.t().contiguous() if bkm else b
+    c = ops.gemm(am, bm, a_kmajor=akm, b_kmajor=bkm)
+    close(c, ref)
+    c32 = ops.gemm(am, bm, a_kmajor=akm, b_kmajor=bkm, out_f32=True)
+    assert c32.dtype == torch.float32
+    close(c32, ref, rel=1e-3, abs_scale=1e-3)
+
+
+def test_gemm_asymmetric_identity(ops):
+    # A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md §3)
+    n = 128
+    a = bf(torch.eye(n, device="cuda"))
+    b = bf(torch.arange(n * n, device="cuda").reshape(n, n).float() % 251)
+    assert torch.equal(ops.gemm(a, b).float(), b.float().t())
+    assert torch.equal(ops.gemm(a, b, b_kmajor=True).float(), b.float())
+
+
+def test_gemm_epilogues(ops):
+    g = torch.Generator(device="cuda").manual_seed(2)
+    M, N, K = 300, 264, 192
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K))
+    bias = bf(torch.randn(N, device="cuda", generator=g))
+    res = bf(torch.randn(M, N, device="cuda", generator=g))
+    z = a.float() @ w.float().t() + bias.float()
+    close(ops.gemm(a, w, bias=bias), z)
+    close(ops.gemm(a, w, bias=bias, act=ops.ACT_RELU), torch.relu(z))
+    close(ops.gemm(a, w, bias=bias, residual=res), z + res.float())
+    y, pre = ops.gemm(a, w, bias=bias, act=ops.ACT_GELU, want_aux=True)
+    close(pre, z)
+    close(y, gelu_ref(z))
+    # backward-style epilogues: mask by relu output / multiply by gelu'(pre)
+    h = bf(torch.relu(torch.randn(M, N, device="cuda", generator=g)))
+    close(ops.gemm(a, w, aux_in=h, dact=ops.ACT_RELU), (a.float() @ w.float().t()) * (h.float() > 0))
+    u = bf(torch.randn(M, N, device="cuda", generator=g))
+    uf = u.float().requires_grad_(True)
+    gelu_ref(uf).sum().backward()
+    close(ops.gemm(a, w, aux_in=u, dact=ops.ACT_GELU), (a.float() @ w.float().t()) * uf.grad)
+
+
+@pytest.mark.parametrize("splitk", [2, 5, 16])
+def test_gemm_splitk_weight_grad_shape(ops, splitk):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Mrows, Dout, Din = 3000, 192, 136          # dW[Dout, Din] = dY^T X, contraction over rows
+    dy = bf(torch.randn(Mrows, Dout, device="cuda", generator=g))
+    x = bf(torch.randn(Mrows, Din, device="cuda", generator=g))
+    ref = dy.float().t() @ x.float()
+    got = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, splitk=splitk)
+    close(got, ref)
+    again = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, splitk=splitk)
+    assert torch.equal(got, again)            # slab reduction is order-fixed: bitwise reproducible
+    close(ops.gemm(dy, x, a_kmajor=True, b_kmajor=True), ref)   # auto split
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from sfcvit._lib import SfcvitError
+    a = bf(torch.randn(16, 12, device="cuda"))
+    with pytest.raises(SfcvitError):
+        ops.gemm(a, a)                          # K = 12 is not a multiple of 8
+    with pytest.raises(SfcvitError):
+        ops.gemm(a.cpu(), a.cpu())              # no CPU fallback
+
+
+@pytest.mark.parametrize("M,D", [(7, 192), (1000, 768), (513, 1024), (64, 128)])
+def test_layernorm(ops, M, D):
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = bf(torch.randn(M, D, device="cuda", generator=g) * 2 + 0.5)
+    gamma = bf(1 + 0.2 * torch.randn(D, device="cuda", generator=g))
+    beta = bf(0.1 * torch.randn(D, device="cuda", generator=g))
+    dy = bf(torch.randn(M, D, device="cuda", generator=g))
+    add = bf(torch.randn(M, D, device="cuda", generator=g))
+    xf = x.float().requires_grad_(True)
+    gf, bfl = gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xf, (D,), gf, bfl, 1e-5)
+    ref.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    close(y, ref.detach())
+    assert torch.allclose(mean, x.float().mean(-1), atol=1e-4)
+    dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gamma)
+    close(dx, xf.grad)
+    close(dg, gf.grad, rel=2e-3, abs_scale=2e-3)
+    close(db, bfl.grad, rel=2e-3, abs_scale=2e-3)
+    dx2, _, _ = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=add)
+    close(dx2, xf.grad + add.float())
+
+
+def test_colsum(ops):
+    x = bf(torch.randn(5000, 328, device="cuda"))
+    close(ops.colsum(x), x.float().sum(0), rel=1e-3, abs_scale=1e-3)
+    v = x[:, 64:192]                               # strided view of a packed buffer
+    close(ops.colsum(v), v.float().sum(0), rel=1e-3, abs_scale=1e-3)
+
+
+def attn_ref(qkv, H):
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // H
+    q, k, v = qkv.float().split(D, dim=-1)
+    sp = lambda t: t.reshape(B, N, H, hd).transpose(1, 2)
+    s = (sp(q) @ sp(k).transpose(-1, -2)) / math.sqrt(hd)
+    p = torch.softmax(s, -1)
+    o = (p @ sp(v)).transpose(1, 2).reshape(B, N, D)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 4, 3), (3, 196, 2), (2, 64, 1), (1, 576, 2), (2, 130, 4)])
+def test_attention(ops, B, N, H):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    qkv = bf(torch.randn(B, N, 3 * H * 64, device="cuda", generator=g))
+    dout = bf(torch.randn(B, N, H * 64, device="cuda", generator=g))
+    qf = qkv.float().requires_grad_(True)
+    ref, lse_ref = attn_ref(qf, H)
+    ref.backward(dout.float())
+    out, lse = ops.attention_fwd(qkv, H)
+    close(out, ref.detach())
+    assert torch.allclose(lse, lse_ref.detach(), atol=2e-2, rtol=1e-2)
+    dqkv = ops.attention_bwd(qkv, out, lse, dout, H)
+    close(dqkv, qf.grad, rel=1.0 / 64, abs_scale=1.0 / 32)
+
+
+def test_attention_spiked_row(ops):
+    # one key dominating one query forces the running-max rescale across key blocks
+    B, N, H = 1, 196, 1
+    g = torch.Generator(device="cuda").manual_seed(6)
+    qkv = torch.randn(B, N, 3 * 64, device="cuda", generator=g)
+    qkv[0, 5, :64] *= 6
+    qkv[0, 150, 64:128] = qkv[0, 5, :64]          # key 150 (third block) aligned with query 5
+    qkv = bf(qkv)
+    ref, _ = attn_ref(qkv, H)
+    out, _ = ops.attention_fwd(qkv, H)
+    close(out, ref)
+
+
+def test_soft_ce(ops):
+    g = torch.Generator(device="cuda").manual_seed(7)
+    B, C, ld = 37, 10, 16
+    logits = torch.zeros(B, ld, device="cuda")
+    logits[:, :C] = torch.randn(B, C, device="cuda", generator=g) * 3
+    logits = bf(logits)
+    t = torch.softmax(torch.randn(B, C, device="cuda", generator=g), -1)
+    lf = logits[:, :C].float().requires_grad_(True)
+    loss = -(t * torch.log_softmax(lf, -1)).sum(-1)
+    loss.mean().backward()
+    rows, dl = ops.soft_ce(logits, t.contiguous(), C, 1.0 / B)
+    assert torch.allclose(rows, loss.detach(), atol=1e-4, rtol=1e-4)
+    close(dl[:, :C], lf.grad)
+    assert not dl[:, C:].any()
+
+
+def test_gelu(ops):
+    x = bf(torch.randn(4096, device="cuda") * 2)
+    dy = bf(torch.randn(4096, device="cuda"))
+    xf = x.float().requires_grad_(True)
+    y = gelu_ref(xf)
+    y.backward(dy.float())
+    close(ops.gelu_fwd(x), y.detach())
+    close(ops.gelu_bwd(dy, x), xf.grad)
+
+
+def test_adamw_and_clip(ops):
+    g = torch.Generator(device="cuda").manual_seed(8)
+    n = 10007
+    w0 = torch.randn(n, device="cuda", generator=g)
+    ref = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.AdamW([ref], lr=3e-4, weight_decay=5e-5)
+    master, m, v = w0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    param = bf(w0)
+    for step in range(1, 4):
+        grad = bf(torch.randn(n, device="cuda", generator=g) * 0.1)
+        ref.grad = grad.float()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        ss = torch.zeros(1, device="cuda")
+        ops.sumsq_accum(grad, ss)
+        assert torch.allclose(ss, grad.float().pow(2).sum(), rtol=1e-4)
+        ops.adamw_step(param, master, grad, m, v, ss, lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-8,
+                       weight_decay=5e-5, max_norm=1.0, step=step)
+        assert torch.allclose(master, ref.detach(), atol=1e-6, rtol=1e-5)
+        assert torch.equal(param, bf(master))
