@@ -1,0 +1,281 @@
+"""Block-level autograd functions of the hot path, built on sfcvit.ops (HIP kernels).
+
+Granularity follows the reference's modules so that every fusion the backward
+needs is local to one function:
+  patch_embed    HilbertEmbedding1D / MortonEmbedding1D / RasterScan1DEmbedding / SFCEmbedding1D .forward
+  mixer_block    MixerBlock.forward                     (src/models/vit.py:268-273)
+  encoder_layer  nn.TransformerEncoderLayer, post-norm  (torch:nn/modules/transformer.py:951-982)
+  predictor_head MultiLayerPredictor(n_layers=2)        (src/models/vit.py:295-319)
+  linear, layer_norm, gelu                              generic pieces
+  soft_target_cross_entropy                             main.py:45-51
+All activations and parameters are bf16 inside; fp32 parameters are cast on entry
+(differentiably), so gradients come back in the parameter's own dtype.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+_BF16 = torch.bfloat16
+
+
+def _bf(t):
+    return t if t is None or t.dtype == _BF16 else t.to(_BF16)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _like(g, ref):
+    """Gradient `g` in the dtype of the tensor it belongs to."""
+    return g if g.dtype == ref.dtype else g.to(ref.dtype)
+
+
+def _wgrad(dy2, x2):
+    """dW[out, in] = dY^T X  (contraction over rows; both operands k-major)."""
+    return ops.gemm(dy2, x2, a_kmajor=True, b_kmajor=True)
+
+
+def _bgrad(dy2):
+    return ops.colsum(dy2).to(_BF16)
+
+
+# ----------------------------------------------------------------------------
+class _PatchEmbed(Function):
+    @staticmethod
+    def forward(ctx, x, pix, w, b):
+        x = _c(x)
+        ctx.save_for_backward(x, pix)
+        ctx.D = w.shape[0]
+        ctx.has_bias = b is not None
+        return ops.patch_embed_fwd(x, pix, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pix = ctx.saved_tensors
+        dw, db = ops.patch_embed_bwd(x, pix, _c(dy), ctx.D, want_bias=ctx.has_bias)
+        return None, None, dw.to(_BF16), (db.to(_BF16) if db is not None else None)
+
+
+def patch_embed(x, pix, weight, bias):
+    """Fused curve gather + patchify + projection: x [B,C,H,W] (fp32 or bf16) -> [B,N,D] bf16."""
+    return _PatchEmbed.apply(x, pix, _bf(weight), _bf(bias))
+
+
+# ----------------------------------------------------------------------------
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x2 = _c(x).view(-1, x.shape[-1])
+        if act == ops.ACT_GELU:
+            y, pre = ops.gemm(x2, w, bias=b, act=act, want_aux=True)
+            ctx.save_for_backward(x2, w, pre)
+        else:
+            y = ops.gemm(x2, w, bias=b, act=act)
+            ctx.save_for_backward(x2, w, y if act == ops.ACT_RELU else None)
+        ctx.act, ctx.has_bias, ctx.shape = act, b is not None, x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, aux = ctx.saved_tensors
+        dy2 = _c(dy).view(-1, dy.shape[-1])
+        if ctx.act == ops.ACT_RELU:
+            dy2 = torch.where(aux > 0, dy2, torch.zeros_like(dy2))
+        elif ctx.act == ops.ACT_GELU:
+            dy2 = ops.gelu_bwd(dy2, aux)
+        dx = ops.gemm(dy2, w, b_kmajor=True).view(ctx.shape)
+        return dx, _wgrad(dy2, x2), (_bgrad(dy2) if ctx.has_bias else None), None
+
+
+def linear(x, weight, bias=None, act=ops.ACT_NONE):
+    return _Linear.apply(_bf(x), _bf(weight), _bf(bias), act)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x2 = _c(x).view(-1, x.shape[-1])
+        y, mean, rstd = ops.layernorm_fwd(x2, w, b, eps)
+        ctx.save_for_backward(x2, mean, rstd, w)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, w = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(_c(dy).view(-1, dy.shape[-1]), x2, mean, rstd, w)
+        return dx.view(dy.shape), dg.to(_BF16), db.to(_BF16), None
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    return _LayerNorm.apply(_bf(x), _bf(weight), _bf(bias), eps)
+
+
+class _Gelu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(_c(dy), x)
+
+
+def gelu(x):
+    return _Gelu.apply(_bf(x))
+
+
+# ----------------------------------------------------------------------------
+class _Mixer(Function):
+    """x + W2 gelu(W1 LN(x) + b1) + b2"""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps):
+        x2 = _c(x).view(-1, x.shape[-1])
+        z, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+        h, u = ops.gemm(z, w1, bias=b1, act=ops.ACT_GELU, want_aux=True)
+        y = ops.gemm(h, w2, bias=b2, residual=x2)
+        ctx.save_for_backward(x2, mean, rstd, z, u, h, ln_w, w1, w2)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, z, u, h, ln_w, w1, w2 = ctx.saved_tensors
+        dy2 = _c(dy).view(-1, dy.shape[-1])
+        dw2, db2 = _wgrad(dy2, h), _bgrad(dy2)
+        du = ops.gemm(dy2, w2, b_kmajor=True, aux_in=u, dact=ops.ACT_GELU)
+        dw1, db1 = _wgrad(du, z), _bgrad(du)
+        dz = ops.gemm(du, w1, b_kmajor=True)
+        dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w, dx_add=dy2)
+        return dx.view(dy.shape), dg.to(_BF16), dbeta.to(_BF16), dw1, db1, dw2, db2, None
+
+
+def mixer_block(x, ln_w, ln_b, w1, b1, w2, b2, eps=1e-5):
+    return _Mixer.apply(_bf(x), _bf(ln_w), _bf(ln_b), _bf(w1), _bf(b1), _bf(w2), _bf(b2), eps)
+
+
+# ----------------------------------------------------------------------------
+class _EncoderLayer(Function):
+    """Post-norm transformer encoder layer, dropout off:
+         a  = out_proj(attention(in_proj(x)));  x1 = LN1(x + a)
+         f  = W2 relu(W1 x1 + b1) + b2;         y  = LN2(x1 + f)"""
+
+    @staticmethod
+    def forward(ctx, x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps):
+        B, N, D = x.shape
+        x2 = _c(x).view(B * N, D)
+        qkv = ops.gemm(x2, in_w, bias=in_b)
+        o, lse = ops.attention_fwd(qkv.view(B, N, 3 * D), n_heads)
+        s1 = ops.gemm(o.view(B * N, D), out_w, bias=out_b, residual=x2)
+        x1, mean1, rstd1 = ops.layernorm_fwd(s1, n1_w, n1_b, eps)
+        h = ops.gemm(x1, w1, bias=b1, act=ops.ACT_RELU)
+        s2 = ops.gemm(h, w2, bias=b2, residual=x1)
+        y, mean2, rstd2 = ops.layernorm_fwd(s2, n2_w, n2_b, eps)
+        ctx.save_for_backward(x2, qkv, o, lse, s1, mean1, rstd1, x1, h, s2, mean2, rstd2,
+                              in_w, out_w, n1_w, w1, w2, n2_w)
+        ctx.n_heads, ctx.shape = n_heads, (B, N, D)
+        return y.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, qkv, o, lse, s1, mean1, rstd1, x1, h, s2, mean2, rstd2,
+         in_w, out_w, n1_w, w1, w2, n2_w) = ctx.saved_tensors
+        B, N, D = ctx.shape
+        dy2 = _c(dy).view(B * N, D)
+        ds2, dg2, dbt2 = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w)
+        dw2, db2 = _wgrad(ds2, h), _bgrad(ds2)
+        dh = ops.gemm(ds2, w2, b_kmajor=True, aux_in=h, dact=ops.ACT_RELU)
+        dw1, db1 = _wgrad(dh, x1), _bgrad(dh)
+        dx1 = ops.gemm(dh, w1, b_kmajor=True, residual=ds2)
+        ds1, dg1, dbt1 = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w)
+        o2 = o.view(B * N, D)
+        dwo, dbo = _wgrad(ds1, o2), _bgrad(ds1)
+        do = ops.gemm(ds1, out_w, b_kmajor=True)
+        dqkv = ops.attention_bwd(qkv.view(B, N, 3 * D), o, lse, do.view(B, N, D), ctx.n_heads).view(B * N, 3 * D)
+        dwi, dbi = _wgrad(dqkv, x2), _bgrad(dqkv)
+        dx = ops.gemm(dqkv, in_w, b_kmajor=True, residual=ds1)
+        return (dx.view(B, N, D), dwi, dbi, dwo, dbo, dg1.to(_BF16), dbt1.to(_BF16), dw1, db1, dw2, db2,
+                dg2.to(_BF16), dbt2.to(_BF16), None, None)
+
+
+def encoder_layer(x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps=1e-5):
+    args = [_bf(t) for t in (x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b)]
+    return _EncoderLayer.apply(*args, n_heads, eps)
+
+
+# ----------------------------------------------------------------------------
+def _pad_rows(t, rows):
+    if t.shape[0] == rows:
+        return t
+    out = torch.zeros((rows,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    out[: t.shape[0]] = t
+    return out
+
+
+class _Head(Function):
+    """LN -> h = z W_emb^T -> y = <h, W_seq> -> GELU -> classifier (Dropout off).
+    The classifier is computed on a class count padded to a multiple of 8 (16-byte rows)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w_emb, w_seq, wc, bc, eps):
+        B, N, D = x.shape
+        R, O, C = w_emb.shape[0], w_seq.shape[0], wc.shape[0]
+        x2 = _c(x).view(B * N, D)
+        z, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+        h = ops.gemm(z, w_emb)                                      # [B*N, R]
+        y1 = ops.gemm(h.view(B, N * R), w_seq.view(O, N * R))      # [B, O]
+        a = ops.gelu_fwd(y1)
+        cpad = (C + 7) // 8 * 8
+        wc_p, bc_p = _pad_rows(wc, cpad), _pad_rows(bc, cpad)
+        logits = ops.gemm(a, wc_p, bias=bc_p)                       # [B, cpad]
+        ctx.save_for_backward(x2, mean, rstd, z, h, y1, a, ln_w, w_emb, w_seq, wc_p)
+        ctx.dims = (B, N, D, R, O, C, cpad)
+        return logits[:, :C]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x2, mean, rstd, z, h, y1, a, ln_w, w_emb, w_seq, wc_p = ctx.saved_tensors
+        B, N, D, R, O, C, cpad = ctx.dims
+        dl = torch.zeros((B, cpad), device=dlogits.device, dtype=_BF16)
+        dl[:, :C] = dlogits
+        dwc = ops.gemm(dl, a, a_kmajor=True, b_kmajor=True)[:C]
+        dbc = ops.colsum(dl)[:C].to(_BF16)
+        da = ops.gemm(dl, wc_p, b_kmajor=True)                      # [B, O]
+        dy1 = ops.gelu_bwd(da, y1)
+        h2 = h.view(B, N * R)
+        dwseq = ops.gemm(dy1, h2, a_kmajor=True, b_kmajor=True).view(O, N, R)
+        dh = ops.gemm(dy1, w_seq.view(O, N * R), b_kmajor=True).view(B * N, R)
+        dwemb = _wgrad(dh, z)
+        dz = ops.gemm(dh, w_emb, b_kmajor=True)
+        dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w)
+        return dx.view(B, N, D), dg.to(_BF16), dbeta.to(_BF16), dwemb, dwseq, dwc, dbc, None
+
+
+def predictor_head(x, ln_w, ln_b, w_emb, w_seq, wc, bc, eps=1e-5):
+    return _Head.apply(_bf(x), _bf(ln_w), _bf(ln_b), _bf(w_emb), _c(_bf(w_seq)), _bf(wc), _bf(bc), eps)
+
+
+# ----------------------------------------------------------------------------
+class _SoftCE(Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        B, C = logits.shape
+        base = _c(logits)                   # [B, C], row stride C (2-byte loads: no alignment needed)
+        rows, dl = ops.soft_ce(base, _c(targets.float()), C, 1.0 / B)
+        ctx.save_for_backward(dl)
+        ctx.C = C
+        return rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl[:, : ctx.C] * g.to(dl.dtype)), None
+
+
+def soft_target_cross_entropy(logits, targets):
+    """-(targets * log_softmax(logits)).sum(-1).mean() with the gradient produced in the same pass."""
+    return _SoftCE.apply(_bf(logits), targets)

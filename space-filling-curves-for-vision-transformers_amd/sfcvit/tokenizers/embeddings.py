@@ -1,0 +1,141 @@
+"""Curve-ordered tokenizers on the fused gather + patchify + projection HIP kernel.
+
+Same constructor signatures, attributes (`n_patches`, `input_dim`, `embed_dim`,
+`proj`) and state_dict keys (index buffers included) as the reference classes:
+  HilbertEmbedding1D     src/tokenizers/_1D/hilbert_embedding1D.py:9-44
+  MortonEmbedding1D      src/tokenizers/_1D/morton_embedding1D.py:9-44
+  MooreEmbedding1D / PeanoEmbedding1D   src/tokenizers/_1D/{moore,peano}_embedding1D.py
+  RasterScan1DEmbedding  src/tokenizers/_1D/zigzag_embedding1D.py:5-39
+  SFCEmbedding1D         src/tokenizers/multiscale/multi_hilbert.py:43-84
+The registered int64 buffer stays the source of truth (it is part of the
+state_dict); the kernel's per-token pixel table is derived from it on the host by
+sfcvit_pixel_table and cached on the device.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from .._lib import lib, check
+from ..curves.space_filling_curves import (curve_table, curve_table_rc, hilbert_curve, moore_curve,
+                                           peano_curve, z_curve)
+from .base_patch_embedding import BasePatchEmbedding
+
+
+def _pixel_table(flat, img, p, g):
+    flat = np.ascontiguousarray(flat, dtype=np.int32)
+    grid = img // p
+    out = np.empty((grid * grid // g, g * p * p), dtype=np.int32)
+    check(lib.sfcvit_pixel_table(flat.ctypes.data_as(ctypes.c_void_p), img, p, g,
+                                 out.ctypes.data_as(ctypes.c_void_p)), "sfcvit_pixel_table")
+    return out
+
+
+class _FusedTokenizer(BasePatchEmbedding):
+    """Holds `proj` and the device copy of the pixel table; subclasses say how the
+    flat curve table is obtained from their registered buffer."""
+
+    def _setup(self, img_size, pre_patch, group, in_channels, embed_dim):
+        self._geom = (img_size, pre_patch, group)
+        self._pix = None
+        self._pix_key = None
+        self.proj = nn.Linear(in_channels * pre_patch * pre_patch * group, embed_dim)
+
+    def _flat_table(self):          # -> 1-D integer array of length grid*grid, or None for raster
+        raise NotImplementedError
+
+    def _pix_table(self, device):
+        buf = self._flat_table()
+        key = (None if buf is None else (buf.data_ptr(), buf._version), str(device))
+        if self._pix is None or self._pix_key != key:
+            img, p, g = self._geom
+            grid = img // p
+            flat = np.arange(grid * grid, dtype=np.int32) if buf is None else buf.detach().cpu().numpy()
+            self._pix = torch.from_numpy(_pixel_table(flat, img, p, g)).to(device)
+            self._pix_key = key
+        return self._pix
+
+    def forward(self, x):
+        img = self._geom[0]
+        if x.dim() != 4 or x.shape[2] != img or x.shape[3] != img:
+            raise ValueError(f"expected [B, C, {img}, {img}] input, got {tuple(x.shape)}")
+        return F.patch_embed(x, self._pix_table(x.device), self.proj.weight, self.proj.bias)
+
+
+class _Curve1D(_FusedTokenizer):
+    _curve = None
+    _buffer = None
+
+    def __init__(self, img_size, patch_size, in_channels, embed_dim):
+        super().__init__()
+        num_pixels = img_size * img_size
+        assert num_pixels % patch_size == 0, "Image must be divisible into 1D patches"
+        self.n_patches = num_pixels // patch_size
+        self.input_dim = in_channels * patch_size
+        self.register_buffer(self._buffer, torch.from_numpy(curve_table_rc(self._curve, img_size)).long())
+        self.embed_dim = embed_dim
+        self._img_size = img_size
+        self._setup(img_size, 1, patch_size, in_channels, embed_dim)
+
+    def _flat_table(self):
+        rc = getattr(self, self._buffer)
+        return rc[:, 0] * self._img_size + rc[:, 1]
+
+
+class HilbertEmbedding1D(_Curve1D):
+    _curve, _buffer = hilbert_curve, "hilbert_indices"
+
+
+class MortonEmbedding1D(_Curve1D):
+    _curve, _buffer = z_curve, "z_indices"
+
+
+class MooreEmbedding1D(_Curve1D):
+    _curve, _buffer = moore_curve, "moore_indices"
+
+
+class PeanoEmbedding1D(_Curve1D):
+    _curve, _buffer = peano_curve, "peano_indices"
+
+
+class RasterScan1DEmbedding(_FusedTokenizer):
+    def __init__(self, img_size, patch_size, in_channels, embed_dim):
+        super().__init__()
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.in_channels = in_channels
+        self.embed_dim = embed_dim
+        num_pixels = img_size * img_size
+        assert num_pixels % patch_size == 0, "Image must be divisible into 1D patches"
+        self.n_patches = num_pixels // patch_size
+        self.input_dim = patch_size * in_channels
+        self._setup(img_size, 1, patch_size, in_channels, embed_dim)
+
+    def _flat_table(self):
+        return None
+
+
+class SFCEmbedding1D(_FusedTokenizer):
+    def __init__(self, img_size, pre_patch_size, group_patch_size, in_channels, embed_dim,
+                 curve_fn=hilbert_curve):
+        super().__init__()
+        assert img_size % pre_patch_size == 0, "Image size must be divisible by pre_patch_size"
+        self.img_size = img_size
+        self.pre_patch_size = pre_patch_size
+        self.group_patch_size = group_patch_size
+        self.in_channels = in_channels
+        self.embed_dim = embed_dim
+        self.curve_fn = curve_fn
+        self.grid_size = img_size // pre_patch_size
+        self.n_pre_patches = self.grid_size * self.grid_size
+        self.n_final_patches = self.n_pre_patches // group_patch_size
+        self.n_patches = self.n_final_patches       # what VisionTransformer{,1D} reads (vit.py:354,422)
+        self.pre_patch_dim = in_channels * pre_patch_size * pre_patch_size
+        self.input_dim = self.pre_patch_dim * group_patch_size
+        self.register_buffer("sfc_indices", torch.from_numpy(curve_table(curve_fn, self.grid_size)).long())
+        self._setup(img_size, pre_patch_size, group_patch_size, in_channels, embed_dim)
+
+    def _flat_table(self):
+        return self.sfc_indices

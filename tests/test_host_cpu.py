@@ -1,0 +1,161 @@
+"""Host-side logic of the product, no GPU: native curve tables against the oracle and
+the golden fixtures, the C-ABI surface, the nn.Module / state_dict surface."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import curves as ocurves
+from oracle.cases import MODEL_CASES, CURVE_KINDS, CURVE_SMALL_N, CURVE_SHA_N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sfc():
+    from sfcvit.curves import space_filling_curves as m
+    return m
+
+
+@pytest.mark.parametrize("kind", CURVE_KINDS)
+@pytest.mark.parametrize("n", CURVE_SMALL_N)
+def test_native_tables_match_golden(kind, n, sfc, golden_dir):
+    small = np.load(os.path.join(golden_dir, "curves_small.npz"))
+    assert np.array_equal(sfc.curve_table(kind, n), small[f"{kind}_{n}"])
+
+
+@pytest.mark.parametrize("kind", ("hilbert", "z"))
+@pytest.mark.parametrize("n", CURVE_SHA_N)
+def test_native_tables_full_size(kind, n, sfc, golden_dir):
+    with open(os.path.join(golden_dir, "curves_sha.json")) as f:
+        sha = json.load(f)
+    assert hashlib.sha256(sfc.curve_table(kind, n).tobytes()).hexdigest() == sha[f"{kind}_{n}"]
+
+
+@pytest.mark.parametrize("kind", CURVE_KINDS)
+@pytest.mark.parametrize("n", [1, 3, 5, 7, 9, 27, 33, 63, 64, 65, 100, 128, 243, 257, 512])
+def test_native_tables_match_oracle(kind, n, sfc):
+    # integer closed forms (product) vs float64 recursion (oracle), ragged and maximum sizes
+    assert np.array_equal(sfc.curve_table(kind, n).astype(np.int64), ocurves.flat_table(kind, n))
+    rc = sfc.curve_table_rc(kind, n)
+    assert np.array_equal(rc, ocurves.embed_and_prune_sfc(kind, n, n))
+
+
+def test_rectangular_embed_and_prune(sfc):
+    for fn, kind in ((sfc.hilbert_curve, "hilbert"), (sfc.z_curve, "z"), (sfc.peano_curve, "peano")):
+        for w, h in ((3, 2), (5, 12), (16, 4), (10, 10)):
+            got = sfc.embed_and_prune_sfc(fn, w, h)
+            ref = [tuple(int(v) for v in p) for p in ocurves.embed_and_prune_sfc(kind, w, h)]
+            assert got == ref
+    with pytest.raises(ValueError):
+        sfc.embed_and_prune_sfc(lambda o, s: [], 4, 4)      # unknown curve, as the reference's grid_size
+
+
+def test_curve_functions_return_cell_centres(sfc):
+    pts = sfc.hilbert_curve(2, size=4)
+    assert len(pts) == 16 and pts[0] == (0.5, 0.5)
+    cells = [(int(np.floor(x)), int(np.floor(y))) for x, y in pts]
+    assert cells == sfc.embed_and_prune_sfc(sfc.hilbert_curve, 4, 4)
+
+
+def test_pixel_table_matches_reference_semantics():
+    from sfcvit.tokenizers.embeddings import _pixel_table
+    from oracle import vit_oracle
+    # p = 2, g = 4 on an 8x8 image: compare with the oracle's rearrange-based tokenisation
+    img, p, g = 8, 2, 4
+    flat = ocurves.flat_table("hilbert", img // p)
+    pix = _pixel_table(flat, img, p, g)
+    x = torch.arange(img * img, dtype=torch.float32).reshape(1, 1, img, img)
+    tok = vit_oracle.tokens_sfc(x, torch.from_numpy(flat), p, g)[0]          # [N, g*p*p] (C = 1)
+    assert np.array_equal(pix, tok.numpy().astype(np.int32))
+
+
+def test_library_exports_every_declared_symbol():
+    from sfcvit import _lib
+    header = open(os.path.join(ROOT, "include", "sfcvit.h")).read()
+    declared = set(re.findall(r"\b(sfcvit_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert _lib.lib.sfcvit_abi_version() == 1
+
+
+def test_argument_checks_run_without_a_gpu():
+    from sfcvit import _lib
+    args = _lib.GemmArgs()
+    assert _lib.lib.sfcvit_gemm(ctypes.byref(args), None) == 1          # SFCVIT_EINVAL, nothing launched
+    assert b"null" in _lib.lib.sfcvit_last_error()
+    out = np.zeros(4, dtype=np.int32)
+    assert _lib.lib.sfcvit_curve_table(99, 2, out.ctypes.data_as(ctypes.c_void_p)) == 1
+    assert _lib.lib.sfcvit_curve_table(0, 0, out.ctypes.data_as(ctypes.c_void_p)) == 1
+
+
+def build_model(cfg):
+    from sfcvit.tokenizers import HilbertEmbedding1D, MortonEmbedding1D, RasterScan1DEmbedding, SFCEmbedding1D
+    from sfcvit.models import VisionTransformer, VisionTransformer1D
+    from sfcvit.curves import hilbert_curve, z_curve
+    if cfg.tokenizer == "hilbert1d":
+        pe = HilbertEmbedding1D(cfg.img_size, cfg.patch_size, cfg.in_channels, cfg.embed_dim)
+    elif cfg.tokenizer == "morton1d":
+        pe = MortonEmbedding1D(cfg.img_size, cfg.patch_size, cfg.in_channels, cfg.embed_dim)
+    elif cfg.tokenizer == "raster1d":
+        pe = RasterScan1DEmbedding(cfg.img_size, cfg.patch_size, cfg.in_channels, cfg.embed_dim)
+    else:
+        pe = SFCEmbedding1D(cfg.img_size, cfg.pre_patch_size, cfg.patch_size, cfg.in_channels, cfg.embed_dim,
+                            {"hilbert": hilbert_curve, "z": z_curve}[cfg.curve])
+    cls = VisionTransformer1D if cfg.variant == "1d" else VisionTransformer
+    return cls(pe, depth=cfg.depth, n_heads=cfg.n_heads, mlp_dim=cfg.mlp_dim, num_classes=cfg.num_classes)
+
+
+@pytest.mark.parametrize("name", sorted(MODEL_CASES))
+def test_state_dict_surface_matches_reference(name, golden_dir):
+    with open(os.path.join(golden_dir, "state_manifest.json")) as f:
+        manifest = json.load(f)[name]
+    cfg, _ = MODEL_CASES[name]
+    model = build_model(cfg)
+    sd = model.state_dict()
+    assert sorted(sd) == sorted(manifest)                   # same keys (fixture is stored sorted)
+    for k, v in sd.items():
+        assert list(v.shape) == manifest[k][0], k
+        assert str(v.dtype).replace("torch.", "") == manifest[k][1], k
+    # the tokenizer is the same module under both names (vit.py:221)
+    assert model.encoder.to_patch_embedding is model.patch_embed
+    assert len(list(model.parameters())) == len({id(p) for p in model.parameters()})
+    # registered index buffer == reference table (bit-exact)
+    from oracle import vit_oracle
+    buf = vit_oracle.curve_buffer(cfg)
+    if buf is not None:
+        assert torch.equal(sd["patch_embed." + cfg.table_key], buf)
+
+
+def test_same_seed_same_init_as_torch_containers():
+    # parameters are created by the same torch constructors in the same order as the reference
+    cfg, _ = MODEL_CASES["hilbert32_1d"]
+    torch.manual_seed(42)
+    a = build_model(cfg).state_dict()
+    torch.manual_seed(42)
+    b = build_model(cfg).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert torch.equal(a["encoder.transformer.layers.0.linear1.weight"], a["encoder.transformer.layers.1.linear1.weight"])
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from sfcvit._lib import SfcvitError
+    cfg, batch = MODEL_CASES["hilbert32_1d"]
+    model = build_model(cfg).eval()
+    with pytest.raises(SfcvitError, match="no CPU fallback"):
+        model(torch.zeros(batch, 3, 32, 32))
+
+
+def test_training_mode_dropout_is_not_silently_skipped():
+    cfg, batch = MODEL_CASES["hilbert32_1d"]
+    model = build_model(cfg).train()
+    with pytest.raises((NotImplementedError, Exception)):
+        model(torch.zeros(batch, 3, 32, 32))
