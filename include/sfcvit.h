@@ -204,6 +204,8 @@ typedef struct sfcvit_adamw_args {
     const float *sumsq; /* device scalar: sum of squares of ALL grads (NULL = no clipping) */
     int64_t n;
     float lr, beta1, beta2, eps, weight_decay, max_norm;
+    float grad_scale;  /* every gradient (and the norm) is multiplied by this first:
+                          1/world_size after a SUM all-reduce, else 1 */
     int32_t step;      /* 1-based */
 } sfcvit_adamw_args;
 int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream);

@@ -302,23 +302,55 @@ __global__ __launch_bounds__(THREADS) void sumsq_kernel(const void *__restrict__
     }
 }
 
-__global__ __launch_bounds__(THREADS) void adamw_kernel(const sfcvit_adamw_args a, float bc1, float bc2) {
-    float clip = 1.f;
+// 8 elements per thread-iteration: bf16 param / grad as one 16-byte vector, fp32 master / m / v
+// as two each.  n_vec = n / 8; the (< 8 element) tail is handled by the first threads.
+__device__ __forceinline__ void adamw_one(float &w, float &m, float &v, float gr, const sfcvit_adamw_args &a, float bc1,
+                                          float rbc2) {
+    w *= 1.f - a.lr * a.weight_decay;
+    m = a.beta1 * m + (1.f - a.beta1) * gr;
+    v = a.beta2 * v + (1.f - a.beta2) * gr * gr;
+    const float denom = sqrtf(v) * rbc2 + a.eps;
+    w -= (a.lr / bc1) * (m / denom);
+}
+
+__global__ __launch_bounds__(THREADS) void adamw_kernel(const sfcvit_adamw_args a, float bc1, float rbc2) {
+    float gmul = a.grad_scale;
     if (a.sumsq) {
-        const float norm = sqrtf(*a.sumsq);
-        clip = fminf(1.f, a.max_norm / (norm + 1e-6f));
+        const float norm = sqrtf(*a.sumsq) * a.grad_scale;
+        gmul *= fminf(1.f, a.max_norm / (norm + 1e-6f));
     }
     uint16_t *p = static_cast<uint16_t *>(a.param);
     const uint16_t *g = static_cast<const uint16_t *>(a.grad);
-    for (int64_t i = blockIdx.x * int64_t(THREADS) + threadIdx.x; i < a.n; i += int64_t(gridDim.x) * THREADS) {
-        const float gr = bf2f(g[i]) * clip;
-        float w = a.master[i];
-        float m = a.m[i], v = a.v[i];
-        w *= 1.f - a.lr * a.weight_decay;
-        m = a.beta1 * m + (1.f - a.beta1) * gr;
-        v = a.beta2 * v + (1.f - a.beta2) * gr * gr;
-        const float denom = sqrtf(v) / sqrtf(bc2) + a.eps;
-        w -= (a.lr / bc1) * (m / denom);
+    const int64_t nvec = a.n >> 3;
+    for (int64_t i = blockIdx.x * int64_t(THREADS) + threadIdx.x; i < nvec; i += int64_t(gridDim.x) * THREADS) {
+        float gr[8], w[8], m[8], v[8];
+        unpack8(reinterpret_cast<const u32x4 *>(g)[i], gr);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const f32x4 wv = reinterpret_cast<const f32x4 *>(a.master)[2 * i + h];
+            const f32x4 mv = reinterpret_cast<const f32x4 *>(a.m)[2 * i + h];
+            const f32x4 vv = reinterpret_cast<const f32x4 *>(a.v)[2 * i + h];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                w[4 * h + j] = wv[j];
+                m[4 * h + j] = mv[j];
+                v[4 * h + j] = vv[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) adamw_one(w[j], m[j], v[j], gr[j] * gmul, a, bc1, rbc2);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            reinterpret_cast<f32x4 *>(a.master)[2 * i + h] = f32x4{w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
+            reinterpret_cast<f32x4 *>(a.m)[2 * i + h] = f32x4{m[4 * h], m[4 * h + 1], m[4 * h + 2], m[4 * h + 3]};
+            reinterpret_cast<f32x4 *>(a.v)[2 * i + h] = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+        }
+        reinterpret_cast<u32x4 *>(p)[i] = pack8(w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < int(a.n & 7)) {
+        const int64_t i = (nvec << 3) + threadIdx.x;
+        float w = a.master[i], m = a.m[i], v = a.v[i];
+        adamw_one(w, m, v, bf2f(g[i]) * gmul, a, bc1, rbc2);
         a.master[i] = w;
         a.m[i] = m;
         a.v[i] = v;
@@ -441,6 +473,9 @@ extern "C" int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream) {
     if (a->n <= 0 || a->step < 1) return fail(SFCVIT_EINVAL, "adamw: n=%lld step=%d", (long long)a->n, a->step);
     const float bc1 = 1.f - powf(a->beta1, float(a->step));
     const float bc2 = 1.f - powf(a->beta2, float(a->step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n)), dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a, bc1, bc2);
+    if (!aligned16(a->param) || !aligned16(a->master) || !aligned16(a->grad) || !aligned16(a->m) || !aligned16(a->v))
+        return fail(SFCVIT_EINVAL, "adamw: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((a->n + 7) / 8)), dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a, bc1,
+                       1.f / sqrtf(bc2));
     return check_launch("adamw");
 }

@@ -41,7 +41,8 @@ class AdamWArgs(ctypes.Structure):
     _fields_ = [("param", c_void_p), ("master", c_void_p), ("grad", c_void_p), ("m", c_void_p),
                 ("v", c_void_p), ("sumsq", c_void_p), ("n", c_int64),
                 ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
-                ("weight_decay", c_float), ("max_norm", c_float), ("step", c_int32)]
+                ("weight_decay", c_float), ("max_norm", c_float), ("grad_scale", c_float),
+                ("step", c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/sfcvit.h declares.

@@ -16,6 +16,39 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 _BF16 = torch.bfloat16
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launching stream (bench.py's roofline
+    leg).  Set `ops.TIMER = KernelTimer()`; every wrapper below then brackets its launch."""
+
+    def __init__(self):
+        self.records = {}
+
+    def launch(self, key, work, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.records.setdefault(key, []).append((e0, e1, work))
+        return out
+
+    def summary(self):
+        """key -> dict(launches, ms_total, ms_avg, work_total); synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for key, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            out[key] = {"launches": len(recs), "ms_total": ms, "ms_avg": ms / len(recs),
+                        "work_total": float(sum(w for _, _, w in recs))}
+        return out
+
+
+TIMER = None
+
+
+def _launch(key, work, fn):
+    return fn() if TIMER is None else TIMER.launch(key, work, fn)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -95,7 +128,8 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
         ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
         args.workspace, args.workspace_bytes = ws.data_ptr(), nbytes
     args.splitk = splitk
-    check(lib.sfcvit_gemm(ctypes.byref(args), _stream()), "sfcvit_gemm")
+    key = "gemm_kernel<%s,%s>" % ("true" if a_kmajor else "false", "true" if b_kmajor else "false")
+    check(_launch(key, 2.0 * M * N * K, lambda: lib.sfcvit_gemm(ctypes.byref(args), _stream())), "sfcvit_gemm")
     return (c, aux) if want_aux else c
 
 
@@ -149,7 +183,8 @@ def attention_fwd(qkv, n_heads):
     a = _lib.AttnArgs()
     a.qkv, a.out, a.lse = qkv.data_ptr(), out.data_ptr(), lse.data_ptr()
     a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
-    check(lib.sfcvit_attention_fwd(ctypes.byref(a), _stream()), "sfcvit_attention_fwd")
+    check(_launch("attn_fwd_kernel", 4.0 * B * n_heads * N * N * hd,
+                  lambda: lib.sfcvit_attention_fwd(ctypes.byref(a), _stream())), "sfcvit_attention_fwd")
     return out, lse
 
 
@@ -164,7 +199,8 @@ def attention_bwd(qkv, out, lse, dout, n_heads):
     a.qkv, a.out, a.lse, a.dout = qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr()
     a.dqkv, a.delta = dqkv.data_ptr(), delta.data_ptr()
     a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
-    check(lib.sfcvit_attention_bwd(ctypes.byref(a), _stream()), "sfcvit_attention_bwd")
+    check(_launch("attn_bwd", 10.0 * B * n_heads * N * N * hd,
+                  lambda: lib.sfcvit_attention_bwd(ctypes.byref(a), _stream())), "sfcvit_attention_bwd")
     return dqkv
 
 
@@ -196,7 +232,8 @@ def patch_embed_fwd(x, pix, w, bias):
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     a.w, a.y, a.workspace, a.workspace_bytes = w.data_ptr(), y.data_ptr(), ws.data_ptr(), nbytes
     a.bias = _need(bias, _BF16, "patch_embed bias", 1).data_ptr() if bias is not None else None
-    check(lib.sfcvit_patch_embed_fwd(ctypes.byref(a), _stream()), "sfcvit_patch_embed_fwd")
+    check(_launch("pe_fwd_kernel", 2.0 * a.B * N * P * a.C * D,
+                  lambda: lib.sfcvit_patch_embed_fwd(ctypes.byref(a), _stream())), "sfcvit_patch_embed_fwd")
     return y
 
 
@@ -211,7 +248,8 @@ def patch_embed_bwd(x, pix, dy, D, want_bias=True):
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     a.y, a.dw, a.dbias = dy.data_ptr(), dw.data_ptr(), (db.data_ptr() if want_bias else None)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
-    check(lib.sfcvit_patch_embed_bwd(ctypes.byref(a), _stream()), "sfcvit_patch_embed_bwd")
+    check(_launch("pe_bwd_kernel", 2.0 * a.B * N * P * a.C * D,
+                  lambda: lib.sfcvit_patch_embed_bwd(ctypes.byref(a), _stream())), "sfcvit_patch_embed_bwd")
     return dw, db
 
 
@@ -253,11 +291,13 @@ def sumsq_accum(g, out):
     check(lib.sfcvit_sumsq_accum(_p(g), g.numel(), int(is_f32), _p(out), _stream()), "sfcvit_sumsq_accum")
 
 
-def adamw_step(param, master, grad, m, v, sumsq, *, lr, beta1, beta2, eps, weight_decay, max_norm, step):
+def adamw_step(param, master, grad, m, v, sumsq, *, lr, beta1, beta2, eps, weight_decay, max_norm, step,
+               grad_scale=1.0):
     a = _lib.AdamWArgs()
     a.param, a.master, a.grad, a.m, a.v = (param.data_ptr(), master.data_ptr(), grad.data_ptr(),
                                            m.data_ptr(), v.data_ptr())
     a.sumsq = sumsq.data_ptr() if sumsq is not None else None
     a.n = param.numel()
     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.max_norm, a.step = lr, beta1, beta2, eps, weight_decay, max_norm, step
+    a.grad_scale = grad_scale
     check(lib.sfcvit_adamw_step(ctypes.byref(a), _stream()), "sfcvit_adamw_step")

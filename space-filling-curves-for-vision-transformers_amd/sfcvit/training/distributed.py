@@ -1,0 +1,112 @@
+"""Data-parallel gradient reduction: one process per GPU, torch.distributed over RCCL
+(backend "nccl" on ROCm) across the xGMI mesh.
+
+The reference has no distributed code; the path shards by images, so
+the only exchange per step is the gradient sum.  Gradients already live in ONE flat
+bf16 buffer (FusedAdamW), so a bucket is a contiguous slice of it: no copies in or
+out.  Buckets are cut in flat order and all-reduced asynchronously as soon as every
+parameter inside has accumulated its gradient (post-accumulate-grad hooks), which
+overlaps the collectives with the rest of backward.  Reduction is SUM; the 1/world
+factor is folded into the optimizer kernel (grad_scale), so clip-by-global-norm sees
+the averaged gradient without an extra pass or a second collective.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): ViT-B has 218 MB of bf16
+gradients per step, i.e. ~0.4-2.5 ms on the wire against >= 20 ms of backward, so a
+few large buckets (default 64 MB) keep per-collective latency negligible and every
+link busy.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, optimizer, bucket_bytes=64 << 20, group=None):
+        self.opt = optimizer
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_bytes = bucket_bytes
+        self.buckets = None          # [(start, end)] element ranges of flat_grad
+        self._pending = None         # per-bucket count of parameters still to arrive
+        self._handles = []
+        self._hooks = []
+        self._param_bucket = {}
+        optimizer.grad_scale = 1.0 / self.world
+
+    # -- bucket plan over the flat gradient buffer ------------------------------------------
+    @staticmethod
+    def plan(sizes, bucket_elems):
+        """Cut consecutive tensors (element counts `sizes`, each padded to a multiple of 8 as in
+        the flat layout) into buckets of at most ~bucket_elems; returns [(first, last_exclusive)]
+        tensor index ranges."""
+        out, start, acc = [], 0, 0
+        for i, n in enumerate(sizes):
+            n = (n + 7) // 8 * 8
+            if acc and acc + n > bucket_elems:
+                out.append((start, i))
+                start, acc = i, 0
+            acc += n
+        if acc:
+            out.append((start, len(sizes)))
+        return out
+
+    def _install(self):
+        views = self.opt.grad_views()
+        elems = max(1, self.bucket_bytes // self.opt.flat_grad.element_size())
+        ranges = self.plan([n for _, n, _ in views], elems)
+        self.buckets, self._members = [], []
+        total = self.opt.flat_grad.numel()
+        for first, last in ranges:
+            s = views[first][0]
+            e = views[last][0] if last < len(views) else total
+            self.buckets.append((s, e))
+            self._members.append(last - first)
+            for _, _, p in views[first:last]:
+                self._param_bucket[id(p)] = len(self.buckets) - 1
+        for _, _, p in views:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def begin_step(self):
+        self._handles = []
+        if self.buckets is not None:
+            self._pending = list(self._members)
+
+    def _on_grad(self, p):
+        if self._pending is None:
+            return
+        b = self._param_bucket[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self.world == 1:
+            return
+        s, e = self.buckets[b]
+        self._handles.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM,
+                                             group=self.group, async_op=True))
+
+    def finish(self):
+        """Block the compute stream on every outstanding collective.  On the first step (flat
+        layout not built yet) the gradients are still separate tensors: build, reduce once,
+        install the hooks."""
+        if self.buckets is None:
+            if self.opt.flat_grad is None:
+                self.opt._build()
+            self._install()
+            if self.world > 1:
+                for b in range(len(self.buckets)):
+                    self._launch(b)
+        elif self._pending is not None and any(self._pending):
+            # a parameter did not fire (e.g. frozen this step): reduce its bucket anyway
+            for b, left in enumerate(self._pending):
+                if left:
+                    self._launch(b)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._pending = None
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

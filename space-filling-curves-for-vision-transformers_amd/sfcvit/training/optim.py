@@ -1,0 +1,148 @@
+"""Fused clip_grad_norm_ + AdamW on flat buffers (src/training/train.py:165-166,
+main.py:288-289 of the reference: clip to 1.0, then AdamW(lr 3e-4, wd 5e-5)).
+
+The reference runs ~150 per-tensor norm kernels with a host sync
+(`clip_grad_norm_(foreach=False)`) and a foreach AdamW.  Here every parameter that
+receives a gradient is a view into one bf16 flat buffer, gradients accumulate into
+a second flat buffer (`p.grad` are views of it), and a step is two kernels: one sum
+of squares, one fused clip + AdamW with fp32 master weights and moments.  Nothing
+synchronises with the host.
+"""
+import torch
+
+from .. import ops
+
+
+class FlatGradBuffer:
+    """Parameters and gradients of a model as views into two flat buffers (device- and
+    dtype-agnostic torch plumbing; FusedAdamW adds the HIP step on top).
+
+    The layout is decided after the first backward: parameters whose .grad is still None then
+    never get one in this model (MixerBlock.token_mix*, src/models/vit.py:269-272) and stay
+    outside the buffers, exactly as torch.optim skips them."""
+
+    def __init__(self, params, grad_scale=1.0):
+        self.params = [p for p in params if p.requires_grad]
+        self.grad_scale = grad_scale            # 1/world_size when grads arrive SUM-reduced
+        self.flat_param = self.flat_grad = None
+        self.active = None                      # parameters that receive gradients, flat order
+        self.offsets = None
+
+    def _check(self, p):
+        pass
+
+    def _build(self):
+        self.active = [p for p in self.params if p.grad is not None]
+        if not self.active:
+            raise RuntimeError("step() before any backward")
+        dev, dtype = self.active[0].device, self.active[0].dtype
+        for p in self.active:
+            self._check(p)
+            if p.dtype != dtype:
+                raise TypeError("all parameters must share one dtype")
+        self.offsets, off = [], 0
+        for p in self.active:
+            self.offsets.append(off)
+            off += (p.numel() + 7) // 8 * 8          # keep every view 16-byte aligned
+        self.flat_param = torch.zeros(off, device=dev, dtype=dtype)
+        self.flat_grad = torch.zeros(off, device=dev, dtype=dtype)
+        for p, o in zip(self.active, self.offsets):
+            k = p.numel()
+            self.flat_param[o:o + k].copy_(p.detach().reshape(-1))
+            self.flat_grad[o:o + k].copy_(p.grad.reshape(-1))
+            p.data = self.flat_param[o:o + k].view(p.shape)
+            p.grad = self.flat_grad[o:o + k].view(p.shape)
+        self._built()
+
+    def _built(self):
+        pass
+
+    def grad_views(self):
+        """[(offset, numel, parameter)] in flat order (used by the data-parallel reducer)."""
+        return [(o, p.numel(), p) for p, o in zip(self.active, self.offsets)]
+
+    def zero_grad(self, set_to_none=False):
+        if self.flat_grad is None:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat_grad.zero_()               # p.grad stay views of the flat buffer
+
+
+class FusedAdamW(FlatGradBuffer):
+    """Not a torch.optim.Optimizer subclass on purpose: state is three flat fp32
+    buffers, not per-tensor dicts.  API: zero_grad(), step(), lr attribute,
+    state_dict() / load_state_dict()."""
+
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-5, max_grad_norm=1.0,
+                 grad_scale=1.0):
+        super().__init__(params, grad_scale)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.step_count = 0
+        self.master = self.m = self.v = self._sumsq = None
+
+    def _check(self, p):
+        if p.dtype != torch.bfloat16 or not p.is_cuda:
+            raise TypeError("FusedAdamW needs bf16 CUDA parameters (model.to('cuda', torch.bfloat16))")
+
+    def _built(self):
+        self.master = self.flat_param.float()
+        self.m = torch.zeros_like(self.master)
+        self.v = torch.zeros_like(self.master)
+        self._sumsq = torch.zeros(1, device=self.master.device, dtype=torch.float32)
+
+    @torch.no_grad()
+    def step(self):
+        if self.flat_grad is None:
+            self._build()
+        self.step_count += 1
+        sumsq = None
+        if self.max_grad_norm is not None:
+            self._sumsq.zero_()
+            ops.sumsq_accum(self.flat_grad, self._sumsq)
+            sumsq = self._sumsq
+        ops.adamw_step(self.flat_param, self.master, self.flat_grad, self.m, self.v, sumsq,
+                       lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                       weight_decay=self.weight_decay, max_norm=self.max_grad_norm or 0.0,
+                       step=self.step_count, grad_scale=self.grad_scale)
+
+    def grad_norm(self):
+        """Total gradient norm of the last step (device tensor; no sync)."""
+        return self._sumsq.sqrt() * self.grad_scale
+
+    def state_dict(self):
+        return {"step": self.step_count, "lr": self.lr, "master": self.master, "m": self.m, "v": self.v}
+
+    def load_state_dict(self, sd):
+        if self.flat_grad is None:
+            raise RuntimeError("run one step before load_state_dict (the flat layout is built then)")
+        self.step_count, self.lr = sd["step"], sd["lr"]
+        self.master.copy_(sd["master"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.flat_param.copy_(self.master)
+
+
+class WarmupCosine:
+    """Linear warm-up then cosine decay, per step (transformers.get_cosine_schedule_with_warmup
+    as used at main.py:310-314; half a cosine period, floor 0)."""
+
+    def __init__(self, optimizer, warmup_steps, total_steps, base_lr=None):
+        import math
+        self.opt, self.warmup, self.total = optimizer, warmup_steps, total_steps
+        self.base = optimizer.lr if base_lr is None else base_lr
+        self.n = 0
+        self._cos = math.cos
+        self._pi = math.pi
+        self.opt.lr = self.lr_at(0)
+
+    def lr_at(self, n):
+        if n < self.warmup:
+            return self.base * n / max(1, self.warmup)
+        prog = (n - self.warmup) / max(1, self.total - self.warmup)
+        return self.base * max(0.0, 0.5 * (1.0 + self._cos(self._pi * prog)))
+
+    def step(self):
+        self.n += 1
+        self.opt.lr = self.lr_at(self.n)
