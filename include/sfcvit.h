@@ -129,6 +129,7 @@ typedef struct sfcvit_gemm_args {
                               shapes); needs `workspace`, allows no epilogue */
     void *workspace;       /* fp32 slabs, sfcvit_gemm_workspace(M, N, splitk) bytes */
     int64_t workspace_bytes;
+    int32_t force_generic; /* testing: 1 = never take the 256-wide LDS-DMA kernel */
 } sfcvit_gemm_args;
 
 int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);

@@ -27,7 +27,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const sfcvit_gemm_args
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const uint16_t *A = static_cast<const uint16_t *>(g.a);
     const uint16_t *B = static_cast<const uint16_t *>(g.b);
     const int kbeg = blockIdx.z * k_per_split;
@@ -139,6 +141,9 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ w
 }
 
 }  // namespace
+
+int gemm256_dispatch(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s);   // gemm256.hip
+
 }  // namespace sfcvit
 
 extern "C" int64_t sfcvit_gemm_workspace(int M, int N, int splitk) {
@@ -177,11 +182,13 @@ extern "C" int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream) {
                         (long long)sfcvit_gemm_workspace(a->M, a->N, splits));
     }
 
-    dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, splits), block(THREADS);
-    if (grid.y > 65535) return fail(SFCVIT_EINVAL, "gemm: M=%d too large", a->M);
-    const size_t lds = 4 * TILE_BYTES;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, s, *a, k_per_split);
+    const int big = (a->force_generic == 1) ? -1 : gemm256_dispatch(*a, splits, k_per_split, s);
+    if (big > 0) return big;
+    dim3 grid(((a->N + BN - 1) / BN) * ((a->M + BM - 1) / BM), 1, splits), block(THREADS);
+    const size_t lds = 4 * TILE_BYTES;
+    if (big == 0) {
+    } else if (!a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, s, *a, k_per_split);
     else if (!a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, s, *a, k_per_split);
     else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, lds, s, *a, k_per_split);
     else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, s, *a, k_per_split);

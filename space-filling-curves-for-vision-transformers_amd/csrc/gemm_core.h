@@ -77,6 +77,15 @@ __device__ __forceinline__ void mma_tile(f32x4 (&acc)[4][4], const char *ia, con
     }
 }
 
+// XCD-aware tile order (cdna_hip_programming.md T1).  Workgroups are dealt round-robin over the
+// 8 XCDs, each with a private L2: block b and b + 8 share one.  The linear tile order (n fastest,
+// so neighbours share the A panel and every tile of a chunk shares the B panel) is cut into 8
+// contiguous chunks, one per XCD; bijective for any tile count.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4][4]) {
 #pragma unroll
     for (int i = 0; i < 4; i++)

@@ -99,7 +99,9 @@ __global__ __launch_bounds__(THREADS, 2) void pe_fwd_kernel(const Geo g, const u
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tiles_n = (D + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int nk = (g.K + BK - 1) / BK;
     f32x4 acc[4][4];
     zero_acc(acc);
@@ -243,7 +245,7 @@ extern "C" int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *st
     hipLaunchKernelGGL(permute_w_kernel, dim3(unsigned((nw + 255) / 256)), dim3(256), 0, s,
                        static_cast<const uint16_t *>(a->w), wp, a->D, a->C, a->P);
     if (int rc = check_launch("patch_embed_fwd permute")) return rc;
-    dim3 grid((a->D + BN - 1) / BN, (g.M + BM - 1) / BM), block(THREADS);
+    dim3 grid(((a->D + BN - 1) / BN) * ((g.M + BM - 1) / BM)), block(THREADS);
     const size_t lds = 4 * TILE_BYTES;
     if (a->x_is_bf16)
         hipLaunchKernelGGL(pe_fwd_kernel<true>, grid, block, lds, s, g, wp, static_cast<const uint16_t *>(a->bias),

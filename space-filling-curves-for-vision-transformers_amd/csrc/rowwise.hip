@@ -161,14 +161,25 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
     }
 }
 
-__global__ void ln_bwd_reduce(const float *__restrict__ partial, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                              int nblocks, int D) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * D) return;
+// Sum of the per-block partials: 32 columns x 8 partial-groups per block, coalesced 128-byte
+// row segments, fixed summation order (bitwise reproducible).
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float *__restrict__ partial, float *__restrict__ dgamma,
+                                                    float *__restrict__ dbeta, int nblocks, int D) {
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int b = 0; b < nblocks; b++) s += partial[size_t(b) * 2 * D + c];
-    if (c < D) dgamma[c] = s;
-    else dbeta[c - D] = s;
+    if (c < 2 * D)
+        for (int b = grp; b < nblocks; b += 8) s += partial[size_t(b) * 2 * D + c];
+    red[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && c < 2 * D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t += red[k][cl];
+        if (c < D) dgamma[c] = t;
+        else dbeta[c - D] = t;
+    }
 }
 
 int ln_bwd_blocks(int M) {
@@ -414,7 +425,7 @@ extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *
     else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, part, M, D);
     else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, part, M, D);
     if (int rc = check_launch("layernorm_bwd")) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 255) / 256), dim3(256), 0, s, part, dgamma, dbeta, nb, D);
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 31) / 32), dim3(256), 0, s, part, dgamma, dbeta, nb, D);
     return check_launch("layernorm_bwd_reduce");
 }
 

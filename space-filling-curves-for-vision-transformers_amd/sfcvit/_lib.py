@@ -28,7 +28,7 @@ class GemmArgs(ctypes.Structure):
                 ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldr", c_int32), ("ldaux", c_int32),
                 ("a_kmajor", c_int32), ("b_kmajor", c_int32), ("act", c_int32), ("dact", c_int32),
                 ("c_is_f32", c_int32), ("splitk", c_int32), ("workspace", c_void_p),
-                ("workspace_bytes", c_int64)]
+                ("workspace_bytes", c_int64), ("force_generic", c_int32)]
 
 
 class AttnArgs(ctypes.Structure):

@@ -83,15 +83,20 @@ def _rows2d(t, dtype, name):
 # GEMM
 # ----------------------------------------------------------------------------
 def auto_splitk(M, N, K):
-    """Split K when the output has too few 128x128 tiles to fill 256 CUs (2 WG/CU)."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    """Split K when the output has too few tiles to fill 256 CUs (weight-gradient shapes)."""
+    if M % 256 == 0 and N % 128 == 0 and K % 64 == 0:        # 256-wide LDS-DMA kernel, 1 WG / CU
+        tiles = (M // 256) * (N // 256 if N % 256 == 0 else N // 128)
+        if tiles >= 200 or K < 2048:
+            return 1
+        return max(1, min(512 // tiles, K // 1024))
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)          # generic 128 x 128 kernel, 2 WG / CU
     if tiles >= 256 or K < 2048:
         return 1
     return max(1, min((768 + tiles - 1) // tiles, K // 512))
 
 
 def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, residual=None,
-         aux_in=None, dact=ACT_NONE, want_aux=False, out_f32=False, splitk=None):
+         aux_in=None, dact=ACT_NONE, want_aux=False, out_f32=False, splitk=None, force_generic=False):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  a: [M,K] (or [K,M] if a_kmajor),
     b: [N,K] (or [K,N] if b_kmajor), bf16.  Returns C (and the pre-activation if want_aux)."""
     _rows2d(a, _BF16, "gemm a")
@@ -128,6 +133,7 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
         ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
         args.workspace, args.workspace_bytes = ws.data_ptr(), nbytes
     args.splitk = splitk
+    args.force_generic = int(force_generic)
     key = "gemm_kernel<%s,%s>" % ("true" if a_kmajor else "false", "true" if b_kmajor else "false")
     check(_launch(key, 2.0 * M * N * K, lambda: lib.sfcvit_gemm(ctypes.byref(args), _stream())), "sfcvit_gemm")
     return (c, aux) if want_aux else c

@@ -1,0 +1,93 @@
+"""The N>1 path on CPU: world_size 2, gloo.  GradReducer + FlatGradBuffer are device-agnostic torch
+plumbing (the HIP step is not involved), so the bucketed, hook-driven all-reduce is exercised here with
+a small fp32 model: the reduced flat gradient must equal the average of the per-rank gradients, over two
+steps (first step = synchronous reduce after the flat layout is built, later steps = hooks)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "space-filling-curves-for-vision-transformers_amd")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _model():
+    torch.manual_seed(7)                      # identical init on every rank
+    m = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.ReLU(), torch.nn.Linear(40, 40), torch.nn.ReLU(),
+                            torch.nn.Linear(40, 8))
+    unused = torch.nn.Linear(3, 3)            # never used in forward: must stay outside the buckets
+    return m, unused
+
+
+def _batch(rank, step):
+    g = torch.Generator().manual_seed(100 + 10 * step + rank)
+    return torch.randn(16, 24, generator=g), torch.randn(16, 8, generator=g)
+
+
+def _worker(rank, world, port, out):
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sfcvit.training.optim import FlatGradBuffer
+    from sfcvit.training.distributed import GradReducer
+    model, unused = _model()
+    buf = FlatGradBuffer(list(model.parameters()) + list(unused.parameters()))
+    red = GradReducer(buf, bucket_bytes=4096)          # several buckets
+    assert buf.grad_scale == 1.0 / world
+    result = []
+    for step in range(3):
+        x, y = _batch(rank, step)
+        buf.zero_grad()
+        red.begin_step()
+        ((model(x) - y) ** 2).mean().backward()
+        red.finish()
+        result.append((buf.flat_grad * buf.grad_scale).clone())
+        assert all(p.grad is None for p in unused.parameters())
+    if rank == 0:
+        torch.save({"grads": result, "buckets": red.buckets, "n": buf.flat_grad.numel()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_bucketed_allreduce_world2(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert len(got["buckets"]) > 1
+    assert got["buckets"][0][0] == 0 and got["buckets"][-1][1] == got["n"]
+    for (s0, e0), (s1, e1) in zip(got["buckets"], got["buckets"][1:]):
+        assert e0 == s1                                  # contiguous cover of the flat buffer
+    # single-process expectation: average over the two ranks' batches
+    for step in range(3):
+        model, _ = _model()
+        ref = None
+        for rank in range(2):
+            model.zero_grad()
+            x, y = _batch(rank, step)
+            ((model(x) - y) ** 2).mean().backward()
+            flat = torch.cat([torch.nn.functional.pad(p.grad.flatten(), (0, (-p.numel()) % 8)) for p in model.parameters()])
+            ref = flat if ref is None else ref + flat
+        ref = ref / 2
+        assert torch.allclose(got["grads"][step], ref, atol=1e-6), step
+
+
+def test_bucket_plan():
+    sys.path.insert(0, PKG)
+    from sfcvit.training.distributed import GradReducer
+    assert GradReducer.plan([10, 100, 1000, 8, 50], 128) == [(0, 2), (2, 3), (3, 5)]
+    assert GradReducer.plan([8], 1) == [(0, 1)]
+    assert GradReducer.plan([], 64) == []

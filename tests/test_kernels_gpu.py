@@ -50,6 +50,43 @@ def test_gemm_layouts(ops, akm, bkm, M, N, K):
     close(c32, ref, rel=1e-3, abs_scale=1e-3)
 
 
+@pytest.mark.parametrize("akm", [False, True])
+@pytest.mark.parametrize("bkm", [False, True])
+@pytest.mark.parametrize("M,N,K,splitk", [(512, 256, 128, 1), (256, 384, 192, 1), (768, 128, 64, 1), (1024, 768, 512, 1),
+                                          (256, 256, 4096, 4), (512, 384, 2048, 3)])
+def test_gemm_large_tile_lds_dma_kernel(ops, akm, bkm, M, N, K, splitk):
+    # shapes eligible for the 256-wide LDS-DMA kernel (gemm256.hip), against fp32 math and
+    # against the generic kernel on the same inputs
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    b = bf(torch.randn(N, K, device="cuda", generator=g))
+    ref = a.float() @ b.float().t()
+    am = a.t().contiguous() if akm else a
+    bm = b.t().contiguous() if bkm else b
+    c = ops.gemm(am, bm, a_kmajor=akm, b_kmajor=bkm, splitk=splitk, force_generic=4)    # 4 = force the large-tile kernel
+    close(c, ref)
+    cg = ops.gemm(am, bm, a_kmajor=akm, b_kmajor=bkm, splitk=splitk, force_generic=True)
+    assert torch.equal(c, cg)          # same k order, same fp32 chain: bit-identical
+
+
+def test_gemm_large_tile_epilogues(ops):
+    g = torch.Generator(device="cuda").manual_seed(12)
+    M, N, K = 512, 384, 256
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K))
+    bias = bf(torch.randn(N, device="cuda", generator=g))
+    res = bf(torch.randn(M, N, device="cuda", generator=g))
+    u = bf(torch.randn(M, N, device="cuda", generator=g))
+    for kw in (dict(bias=bias), dict(bias=bias, act=ops.ACT_RELU), dict(bias=bias, residual=res),
+               dict(bias=bias, act=ops.ACT_GELU), dict(aux_in=u, dact=ops.ACT_RELU), dict(aux_in=u, dact=ops.ACT_GELU),
+               dict(residual=res, out_f32=True)):
+        assert torch.equal(ops.gemm(a, w, force_generic=4, **kw), ops.gemm(a, w, force_generic=True, **kw)), kw
+    y, pre = ops.gemm(a, w, bias=bias, act=ops.ACT_GELU, want_aux=True, force_generic=4)
+    yg, preg = ops.gemm(a, w, bias=bias, act=ops.ACT_GELU, want_aux=True, force_generic=True)
+    assert torch.equal(y, yg) and torch.equal(pre, preg)
+    close(pre, a.float() @ w.float().t() + bias.float())
+
+
 def test_gemm_asymmetric_identity(ops):
     # A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md §3)
     n = 128
