@@ -7,7 +7,8 @@
 
 Workload (BASELINE.json configs[2] / [3]): ViT-B/16 at 224x224, Hilbert pixel order
 (HilbertEmbedding1D(224, 256, 3, 768) + VisionTransformer1D(depth 12, heads 12, mlp 3072,
-1000 classes)), 256 synthetic images per GPU, one full training step = zero_grad ->
+1000 classes)), 256 synthetic images per GPU, training mode with the reference's dropout
+(0.1 at the four encoder sites, 0.5 in the head), one full training step = zero_grad ->
 forward -> soft-target CE -> backward -> (gradient all-reduce) -> clip 1.0 -> AdamW.
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline`
 (the dominant kernel, timed live with HIP events) and `cpu_baseline` (the oracle's
@@ -90,7 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="vit_b16_224_hilbert", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
-    ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--dropout", type=float, default=0.1,
+                    help="encoder dropout (reference default 0.1; the head then uses the reference's 0.5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)

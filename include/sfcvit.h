@@ -108,7 +108,7 @@ int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *stream);
  *   a_kmajor = 0: A is [M, lda] with k contiguous;  1: A is [K, lda] with m contiguous
  *   b_kmajor = 0: B is [N, ldb] with k contiguous;  1: B is [K, ldb] with n contiguous
  *   epilogue, in this order (fp32):  v += bias[n];  aux_out[m,n] = bf16(v);
- *   v = act(v);  v += residual[m,n];  v *= dact(aux_in[m,n]);  C[m,n] = v
+ *   v = act(v);  v = dropout(v);  v += residual[m,n];  v *= dact(aux_in[m,n]) * dact_scale;  C[m,n] = v
  * ---------------------------------------------------------------------- */
 enum sfcvit_act { SFCVIT_ACT_NONE = 0, SFCVIT_ACT_RELU = 1, SFCVIT_ACT_GELU = 2 };
 /* dact: 0 none; RELU: (aux_in > 0); GELU: gelu'(aux_in) (erf form, nn.GELU default) */
@@ -129,7 +129,10 @@ typedef struct sfcvit_gemm_args {
                               shapes); needs `workspace`, allows no epilogue */
     void *workspace;       /* fp32 slabs, sfcvit_gemm_workspace(M, N, splitk) bytes */
     int64_t workspace_bytes;
-    int32_t force_generic; /* testing: 1 = never take the 256-wide LDS-DMA kernel */
+    int32_t force_generic; /* testing: 1 = never take the 256-wide LDS-DMA kernel, 4 = always */
+    float dropout_p;       /* > 0: after act, before residual: v = keep(m, n) ? v / (1 - p) : 0 (nn.Dropout, training) */
+    uint32_t dropout_seed;
+    float dact_scale;      /* multiplies v together with dact (0 = 1): 1/(1-p) of a dropout that followed the ReLU */
 } sfcvit_gemm_args;
 
 int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);
@@ -152,6 +155,12 @@ int sfcvit_layernorm_fwd(const void *x, const void *gamma, const void *beta, voi
 int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const float *rstd,
                          const void *gamma, const void *dx_add, void *dx, float *dgamma,
                          float *dbeta, int M, int D, void *ws, void *stream);
+/* Same, plus dx_drop[m, d] = keep(m, d) ? dx / (1 - p) : 0 (bf16): the gradient entering a sub-layer
+ * whose output went through nn.Dropout(p) before the residual add (dropout1 / dropout2,
+ * torch:nn/modules/transformer.py:953-957), mask regenerated from `seed`. */
+int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, const float *rstd,
+                              const void *gamma, const void *dx_add, void *dx, void *dx_drop, float p,
+                              uint32_t seed, float *dgamma, float *dbeta, int M, int D, void *ws, void *stream);
 int64_t sfcvit_layernorm_bwd_ws(int M, int D);
 
 /* ------------------------------------------------------------------------
@@ -169,6 +178,9 @@ typedef struct sfcvit_attn_args {
     float *delta;     /* bwd: workspace [B, H, N] fp32 */
     int32_t B, N, H, hd;
     float scale;      /* 1/sqrt(hd) */
+    float dropout_p;  /* > 0: dropout on the attention probabilities (SDPA dropout_p, training mode);
+                         row = (b*H + h)*N + q, col = key of the mask function */
+    uint32_t dropout_seed;
 } sfcvit_attn_args;
 
 int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream);
@@ -181,6 +193,11 @@ int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream);
 int sfcvit_gelu_fwd(const void *x, void *y, int64_t n, void *stream);
 /* dx = dy * gelu'(x) */
 int sfcvit_gelu_bwd(const void *dy, const void *x, void *dx, int64_t n, void *stream);
+/* GELU followed by nn.Dropout(p) (MultiLayerPredictor, vit.py:308-309) on a [rows, cols] tensor, cols % 8 == 0. */
+int sfcvit_gelu_drop_fwd(const void *x, void *y, int rows, int cols, float p, uint32_t seed, void *stream);
+int sfcvit_gelu_drop_bwd(const void *dy, const void *x, void *dx, int rows, int cols, float p, uint32_t seed, void *stream);
+/* The keep mask itself, as bf16 {0, 1/(1-p)} (tests and debugging): out [rows, cols]. */
+int sfcvit_dropout_mask(void *out, int64_t rows, int cols, float p, uint32_t seed, void *stream);
 
 /* SoftTargetCrossEntropy (main.py:45-51), forward and gradient in one pass.
  * logits bf16 [B, ld] (first C columns used), targets fp32 [B, C];

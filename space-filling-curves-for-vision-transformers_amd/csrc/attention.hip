@@ -121,6 +121,12 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(const sfcvit_attn_arg
     const uint16_t *qp = base, *kp = base + D, *vp = base + 2 * D;
     const int q0 = blockIdx.x * BLK + wave * 16;
     const float scale = a.scale;
+    const bool drop = a.dropout_p > 0.f;
+    const uint32_t dth = drop_thresh(a.dropout_p);
+    const float dsc = 1.f / (1.f - a.dropout_p);
+    // mask row of this lane's query, in pairs of keys
+    const uint64_t drow = (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q0 + (lane & 15));
+    const uint64_t dpair_row = drow * uint64_t((N + 1) >> 1);
 
     bf16x8 qf[2];
     qf[0] = global_frag(qp, ld, q0, N, 0, lane);
@@ -166,8 +172,19 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(const sfcvit_attn_arg
                 s[kf][r] = __expf(s[kf][r] - m_new);
                 ls += s[kf][r];
             }
-        l_run = l_run * alpha + ls;
+        l_run = l_run * alpha + ls;      // the normaliser uses the un-dropped probabilities
         m_run = m_new;
+        if (drop) {
+#pragma unroll
+            for (int kf = 0; kf < 4; kf++) {
+                const uint64_t pr = dpair_row + uint64_t((k0 + 16 * kf + 4 * (lane >> 4)) >> 1);
+                bool k[4];
+                drop_keep2(a.dropout_seed, pr, dth, k[0], k[1]);
+                drop_keep2(a.dropout_seed, pr + 1, dth, k[2], k[3]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) s[kf][r] = k[r] ? s[kf][r] * dsc : 0.f;
+            }
+        }
 #pragma unroll
         for (int hf = 0; hf < 4; hf++) o[hf] *= alpha;
 #pragma unroll
@@ -230,6 +247,11 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(const sfcvit_attn_
     const float *lse = a.lse + (size_t(b) * a.H + h) * N, *del = a.delta + (size_t(b) * a.H + h) * N;
     const int key0 = blockIdx.x * BLK + wave * 16;
     const float scale = a.scale;
+    const bool drop = a.dropout_p > 0.f;
+    const uint32_t dth = drop_thresh(a.dropout_p);
+    const float dsc = 1.f / (1.f - a.dropout_p);
+    const int dkey = key0 + (lane & 15);
+    const uint64_t dbh = (uint64_t(b) * a.H + h) * uint64_t(N);
 
     bf16x8 kf[2], vf[2];
 #pragma unroll
@@ -267,8 +289,14 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(const sfcvit_attn_
                 for (int r = 0; r < 4; r++) {
                     const int ql = 16 * qf + 4 * (lane >> 4) + r;
                     const float pv = __expf(s[r] * scale - lse_s[ql]);
-                    p[t][r] = pv;
-                    ds[t][r] = pv * (dp[r] - del_s[ql]) * scale;
+                    float keep = 1.f;
+                    if (drop) {
+                        bool k0b, k1b;
+                        drop_keep2(a.dropout_seed, (dbh + uint64_t(q0 + ql)) * uint64_t((N + 1) >> 1) + uint64_t(dkey >> 1), dth, k0b, k1b);
+                        keep = ((dkey & 1) ? k1b : k0b) ? dsc : 0.f;
+                    }
+                    p[t][r] = pv * keep;                                   // dropped probabilities feed dV
+                    ds[t][r] = pv * (dp[r] * keep - del_s[ql]) * scale;
                 }
             }
             const bf16x8 pf = pack_frag(p[0], p[1]), dsf = pack_frag(ds[0], ds[1]);
@@ -303,6 +331,10 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(const sfcvit_attn_a
     const float scale = a.scale;
     const float lse_q = q < N ? a.lse[(size_t(b) * a.H + h) * N + q] : 0.f;
     const float del_q = q < N ? a.delta[(size_t(b) * a.H + h) * N + q] : 0.f;
+    const bool drop = a.dropout_p > 0.f;
+    const uint32_t dth = drop_thresh(a.dropout_p);
+    const float dsc = 1.f / (1.f - a.dropout_p);
+    const uint64_t dpair_row = ((uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q)) * uint64_t((N + 1) >> 1);
 
     bf16x8 qf[2], dof[2];
 #pragma unroll
@@ -332,8 +364,17 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(const sfcvit_attn_a
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag(vimg, 16 * kfi, kk, lane), dof[kk], dp, 0, 0, 0);
                 }
                 // s[r] = S^T[key = k0 + 16kfi + 4g + r][q]; keys >= N have K = V = 0 and add nothing
+                float keep[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop) {
+                    const uint64_t pr = dpair_row + uint64_t((k0 + 16 * kfi + 4 * (lane >> 4)) >> 1);
+                    bool k[4];
+                    drop_keep2(a.dropout_seed, pr, dth, k[0], k[1]);
+                    drop_keep2(a.dropout_seed, pr + 1, dth, k[2], k[3]);
 #pragma unroll
-                for (int r = 0; r < 4; r++) ds[t][r] = __expf(s[r] * scale - lse_q) * (dp[r] - del_q) * scale;
+                    for (int r = 0; r < 4; r++) keep[r] = k[r] ? dsc : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) ds[t][r] = __expf(s[r] * scale - lse_q) * (dp[r] * keep[r] - del_q) * scale;
             }
             const bf16x8 dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
@@ -350,6 +391,7 @@ int check_args(const sfcvit_attn_args *a, const char *what, bool bwd) {
     if (!a || !a->qkv || !a->out || !a->lse) return fail(SFCVIT_EINVAL, "%s: null pointer", what);
     if (bwd && (!a->dout || !a->dqkv || !a->delta)) return fail(SFCVIT_EINVAL, "%s: null pointer", what);
     if (a->hd != HD) return fail(SFCVIT_EINVAL, "%s: head dim %d not supported (this build: 64)", what, a->hd);
+    if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return fail(SFCVIT_EINVAL, "%s: dropout_p=%g out of [0, 1)", what, a->dropout_p);
     if (a->B <= 0 || a->N <= 0 || a->H <= 0 || a->B > 65535 || a->H > 65535)
         return fail(SFCVIT_EINVAL, "%s: B=%d N=%d H=%d", what, a->B, a->N, a->H);
     if (!aligned16(a->qkv) || !aligned16(a->out) || (bwd && (!aligned16(a->dout) || !aligned16(a->dqkv))))

@@ -65,6 +65,26 @@ __device__ __forceinline__ bf16x8 st_frag(const char *img, int col0, int kk, int
     return r;
 }
 
+// ---- counter-based dropout mask ------------------------------------------------
+// Element (row, col) of a [rows, cols] tensor belongs to pair index row * ceil(cols/2) + col/2;
+// one 32-bit hash per pair gives two 16-bit uniforms; keep iff u16 >= thresh, thresh = p * 65536.
+// The same function is evaluated in forward and backward (nothing is stored) and by
+// sfcvit_dropout_mask (tests).  Statistical quality: murmur3 finaliser of (pair, seed).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint64_t pair) {
+    return mix32(uint32_t(pair) * 0x9E3779B1u + mix32(seed + uint32_t(pair >> 32) * 0x7FEB352Du));
+}
+__device__ __forceinline__ uint32_t drop_thresh(float p) { return uint32_t(p * 65536.f + 0.5f); }
+// keep flags of the two elements of a pair
+__device__ __forceinline__ void drop_keep2(uint32_t seed, uint64_t pair, uint32_t thresh, bool &k0, bool &k1) {
+    const uint32_t h = drop_hash(seed, pair);
+    k0 = (h & 0xFFFFu) >= thresh;
+    k1 = (h >> 16) >= thresh;
+}
+
 // 64-lane butterfly reductions.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -69,56 +69,16 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const sfcvit_gemm_args
 
     // Epilogue (N % 4 == 0 is checked on the host: a 4-vector is entirely inside or outside).
     const uint16_t *bias = static_cast<const uint16_t *>(g.bias);
-    const uint16_t *res = static_cast<const uint16_t *>(g.residual);
-    const uint16_t *auxi = static_cast<const uint16_t *>(g.aux_in);
-    uint16_t *auxo = static_cast<uint16_t *>(g.aux_out);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
         if (n >= g.N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            const u32x2 b2 = *reinterpret_cast<const u32x2 *>(bias + n);
-            bv[0] = bf2f(uint16_t(b2[0])); bv[1] = bf2f(uint16_t(b2[0] >> 16));
-            bv[2] = bf2f(uint16_t(b2[1])); bv[3] = bf2f(uint16_t(b2[1] >> 16));
-        }
+        float bv[4];
+        load_bias4(bias, n, bv);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-            if (m >= g.M) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
-            if (auxo) {
-                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                *reinterpret_cast<u32x2 *>(auxo + size_t(m) * g.ldaux + n) = o;
-            }
-            if (g.act == SFCVIT_ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-            } else if (g.act == SFCVIT_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = gelu_erf(v[r]);
-            }
-            if (res) {
-                const u32x2 r2 = *reinterpret_cast<const u32x2 *>(res + size_t(m) * g.ldr + n);
-                v[0] += bf2f(uint16_t(r2[0])); v[1] += bf2f(uint16_t(r2[0] >> 16));
-                v[2] += bf2f(uint16_t(r2[1])); v[3] += bf2f(uint16_t(r2[1] >> 16));
-            }
-            if (g.dact != SFCVIT_ACT_NONE) {
-                const u32x2 a2 = *reinterpret_cast<const u32x2 *>(auxi + size_t(m) * g.ldaux + n);
-                const float a[4] = {bf2f(uint16_t(a2[0])), bf2f(uint16_t(a2[0] >> 16)), bf2f(uint16_t(a2[1])),
-                                    bf2f(uint16_t(a2[1] >> 16))};
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    v[r] = (g.dact == SFCVIT_ACT_RELU) ? (a[r] > 0.f ? v[r] : 0.f) : v[r] * gelu_erf_grad(a[r]);
-            }
-            if (g.c_is_f32) {
-                *reinterpret_cast<f32x4 *>(static_cast<float *>(g.c) + size_t(m) * g.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                *reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n) = o;
-            }
+            if (m < g.M) epilogue4(g, m, n, acc[i][j], bv);
         }
     }
 }
@@ -169,13 +129,14 @@ extern "C" int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream) {
     if (a->dact != SFCVIT_ACT_NONE && !a->aux_in) return fail(SFCVIT_EINVAL, "gemm: dact needs aux_in");
     if (a->act < 0 || a->act > 2 || a->dact < 0 || a->dact > 2) return fail(SFCVIT_EINVAL, "gemm: bad act/dact");
     if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 7)) return fail(SFCVIT_EINVAL, "gemm: bias alignment");
+    if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return fail(SFCVIT_EINVAL, "gemm: dropout_p=%g out of [0, 1)", a->dropout_p);
     int splits = a->splitk < 1 ? 1 : a->splitk;
     const int ktiles = (a->K + BK - 1) / BK;
     if (splits > ktiles) splits = ktiles;
     int k_per_split = ((ktiles + splits - 1) / splits) * BK;
     splits = (a->K + k_per_split - 1) / k_per_split;
     if (splits > 1) {
-        if (a->bias || a->residual || a->aux_out || a->act || a->dact)
+        if (a->bias || a->residual || a->aux_out || a->act || a->dact || a->dropout_p > 0.f)
             return fail(SFCVIT_EINVAL, "gemm: split-K supports no epilogue");
         if (!a->workspace || a->workspace_bytes < sfcvit_gemm_workspace(a->M, a->N, splits) || !aligned16(a->workspace))
             return fail(SFCVIT_EINVAL, "gemm: split-K workspace too small (%lld bytes needed)",

@@ -123,55 +123,13 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const sfcvit_gemm_args
         return;
     }
     const uint16_t *bias = static_cast<const uint16_t *>(g.bias);
-    const uint16_t *res = static_cast<const uint16_t *>(g.residual);
-    const uint16_t *auxi = static_cast<const uint16_t *>(g.aux_in);
-    uint16_t *auxo = static_cast<uint16_t *>(g.aux_out);
 #pragma unroll
     for (int j = 0; j < NF; j++) {
         const int n = n0 + wn * (BN_ / 4) + j * 16 + 4 * (lane >> 4);
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            const u32x2 b2 = *reinterpret_cast<const u32x2 *>(bias + n);
-            bv[0] = bf2f(uint16_t(b2[0])); bv[1] = bf2f(uint16_t(b2[0] >> 16));
-            bv[2] = bf2f(uint16_t(b2[1])); bv[3] = bf2f(uint16_t(b2[1] >> 16));
-        }
+        float bv[4];
+        load_bias4(bias, n, bv);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int m = m0 + wm * 128 + i * 16 + (lane & 15);
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv[r];
-            if (auxo) {
-                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                *reinterpret_cast<u32x2 *>(auxo + size_t(m) * g.ldaux + n) = o;
-            }
-            if (g.act == SFCVIT_ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-            } else if (g.act == SFCVIT_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = gelu_erf(v[r]);
-            }
-            if (res) {
-                const u32x2 r2 = *reinterpret_cast<const u32x2 *>(res + size_t(m) * g.ldr + n);
-                v[0] += bf2f(uint16_t(r2[0])); v[1] += bf2f(uint16_t(r2[0] >> 16));
-                v[2] += bf2f(uint16_t(r2[1])); v[3] += bf2f(uint16_t(r2[1] >> 16));
-            }
-            if (g.dact != SFCVIT_ACT_NONE) {
-                const u32x2 a2 = *reinterpret_cast<const u32x2 *>(auxi + size_t(m) * g.ldaux + n);
-                const float a[4] = {bf2f(uint16_t(a2[0])), bf2f(uint16_t(a2[0] >> 16)), bf2f(uint16_t(a2[1])),
-                                    bf2f(uint16_t(a2[1] >> 16))};
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    v[r] = (g.dact == SFCVIT_ACT_RELU) ? (a[r] > 0.f ? v[r] : 0.f) : v[r] * gelu_erf_grad(a[r]);
-            }
-            if (g.c_is_f32) {
-                *reinterpret_cast<f32x4 *>(static_cast<float *>(g.c) + size_t(m) * g.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                *reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n) = o;
-            }
-        }
+        for (int i = 0; i < 8; i++) epilogue4(g, m0 + wm * 128 + i * 16 + (lane & 15), n, acc[i][j], bv);
     }
 }
 

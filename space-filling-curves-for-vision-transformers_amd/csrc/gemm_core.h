@@ -6,6 +6,7 @@
 //   acc[i][j][r] = C[m][n],  m = wm*64 + i*16 + (lane & 15),  n = wn*64 + j*16 + 4*(lane >> 4) + r
 // i.e. a lane owns 4 consecutive n of one m (8-byte bf16 / 16-byte fp32 epilogue vectors).
 #pragma once
+#include "../../include/sfcvit.h"
 #include "device_common.h"
 
 namespace sfcvit {
@@ -106,6 +107,63 @@ __device__ __forceinline__ void store_partial(const f32x4 (&acc)[4][4], float *s
             const int m = m0 + wm * 64 + i * 16 + (lane & 15);
             if (m < M) *reinterpret_cast<f32x4 *>(slab + size_t(m) * N + n) = acc[i][j];
         }
+    }
+}
+
+// Bias of 4 consecutive columns as fp32.
+__device__ __forceinline__ void load_bias4(const uint16_t *bias, int n, float (&bv)[4]) {
+    bv[0] = bv[1] = bv[2] = bv[3] = 0.f;
+    if (bias) {
+        const u32x2 b2 = *reinterpret_cast<const u32x2 *>(bias + n);
+        bv[0] = bf2f(uint16_t(b2[0])); bv[1] = bf2f(uint16_t(b2[0] >> 16));
+        bv[2] = bf2f(uint16_t(b2[1])); bv[3] = bf2f(uint16_t(b2[1] >> 16));
+    }
+}
+
+// Fused epilogue of one 4-vector C[m][n..n+3] (order documented at sfcvit_gemm in include/sfcvit.h).
+__device__ __forceinline__ void epilogue4(const sfcvit_gemm_args &g, int m, int n, const f32x4 &acc, const float (&bv)[4]) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = acc[r] + bv[r];
+    if (g.aux_out) {
+        u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(g.aux_out) + size_t(m) * g.ldaux + n) = o;
+    }
+    if (g.act == SFCVIT_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+    } else if (g.act == SFCVIT_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = gelu_erf(v[r]);
+    }
+    if (g.dropout_p > 0.f) {
+        const uint32_t th = drop_thresh(g.dropout_p);
+        const float sc = 1.f / (1.f - g.dropout_p);
+        const uint64_t pair = uint64_t(m) * uint64_t((g.N + 1) >> 1) + uint64_t(n >> 1);
+        bool k[4];
+        drop_keep2(g.dropout_seed, pair, th, k[0], k[1]);
+        drop_keep2(g.dropout_seed, pair + 1, th, k[2], k[3]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = k[r] ? v[r] * sc : 0.f;
+    }
+    if (g.residual) {
+        const u32x2 r2 = *reinterpret_cast<const u32x2 *>(static_cast<const uint16_t *>(g.residual) + size_t(m) * g.ldr + n);
+        v[0] += bf2f(uint16_t(r2[0])); v[1] += bf2f(uint16_t(r2[0] >> 16));
+        v[2] += bf2f(uint16_t(r2[1])); v[3] += bf2f(uint16_t(r2[1] >> 16));
+    }
+    if (g.dact != SFCVIT_ACT_NONE) {
+        const u32x2 a2 = *reinterpret_cast<const u32x2 *>(static_cast<const uint16_t *>(g.aux_in) + size_t(m) * g.ldaux + n);
+        const float a[4] = {bf2f(uint16_t(a2[0])), bf2f(uint16_t(a2[0] >> 16)), bf2f(uint16_t(a2[1])), bf2f(uint16_t(a2[1] >> 16))};
+        const float ds = g.dact_scale != 0.f ? g.dact_scale : 1.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            v[r] = (g.dact == SFCVIT_ACT_RELU) ? (a[r] > 0.f ? v[r] * ds : 0.f) : v[r] * gelu_erf_grad(a[r]) * ds;
+    }
+    if (g.c_is_f32) {
+        *reinterpret_cast<f32x4 *>(static_cast<float *>(g.c) + size_t(m) * g.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+        u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n) = o;
     }
 }
 

@@ -88,8 +88,11 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                                                          const float *__restrict__ mean, const float *__restrict__ rstd,
                                                          const uint16_t *__restrict__ gamma,
                                                          const uint16_t *__restrict__ dx_add, uint16_t *__restrict__ dx,
+                                                         uint16_t *__restrict__ dx_drop, float drop_p, uint32_t drop_seed,
                                                          float *__restrict__ partial, int M, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [WAVES][2][D] fp32
+    const uint32_t drop_th = drop_thresh(drop_p);
+    const float drop_sc = 1.f / (1.f - drop_p);
     float *red = reinterpret_cast<float *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D >> 3;
@@ -138,6 +141,17 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                     for (int j = 0; j < 8; j++) o[j] += a[j];
                 }
                 *reinterpret_cast<u32x4 *>(dx + size_t(row) * D + c * 8) = pack8(o);
+                if (dx_drop) {
+                    const uint64_t pair0 = uint64_t(row) * uint64_t(D >> 1) + uint64_t(c * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        bool k0, k1;
+                        drop_keep2(drop_seed, pair0 + q, drop_th, k0, k1);
+                        o[2 * q] = k0 ? o[2 * q] * drop_sc : 0.f;
+                        o[2 * q + 1] = k1 ? o[2 * q + 1] * drop_sc : 0.f;
+                    }
+                    *reinterpret_cast<u32x4 *>(dx_drop + size_t(row) * D + c * 8) = pack8(o);
+                }
             }
         }
     }
@@ -238,6 +252,57 @@ __global__ __launch_bounds__(THREADS) void gelu_kernel(const uint16_t *__restric
             for (int j = 0; j < 8; j++) o[j] = gelu_erf(xv[j]);
         }
         *reinterpret_cast<u32x4 *>(out + i * 8) = pack8(o);
+    }
+}
+
+// GELU followed by dropout on a [rows, cols] tensor (cols % 8 == 0); one 8-vector per thread-iteration.
+template <bool BWD>
+__global__ __launch_bounds__(THREADS) void gelu_drop_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                            uint16_t *__restrict__ out, int rows, int cols, float p,
+                                                            uint32_t seed) {
+    const uint32_t th = drop_thresh(p);
+    const float sc = 1.f / (1.f - p);
+    const int vpr = cols >> 3;
+    const int64_t nvec = int64_t(rows) * vpr;
+    for (int64_t i = blockIdx.x * int64_t(THREADS) + threadIdx.x; i < nvec; i += int64_t(gridDim.x) * THREADS) {
+        const int64_t row = i / vpr;
+        const int cv = int(i - row * vpr);
+        float xv[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4 *>(x + i * 8), xv);
+        if (BWD) {
+            float dv[8];
+            unpack8(*reinterpret_cast<const u32x4 *>(dy + i * 8), dv);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = dv[j] * gelu_erf_grad(xv[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = gelu_erf(xv[j]);
+        }
+        const uint64_t pair0 = uint64_t(row) * uint64_t(cols >> 1) + uint64_t(cv * 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bool k0, k1;
+            drop_keep2(seed, pair0 + q, th, k0, k1);
+            o[2 * q] = k0 ? o[2 * q] * sc : 0.f;
+            o[2 * q + 1] = k1 ? o[2 * q + 1] * sc : 0.f;
+        }
+        *reinterpret_cast<u32x4 *>(out + i * 8) = pack8(o);
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void dropout_mask_kernel(uint16_t *__restrict__ out, int64_t rows, int cols, float p,
+                                                               uint32_t seed) {
+    const uint32_t th = drop_thresh(p);
+    const uint16_t on = f2bf(1.f / (1.f - p));
+    const int ppr = (cols + 1) >> 1;
+    const int64_t npair = rows * ppr;
+    for (int64_t i = blockIdx.x * int64_t(THREADS) + threadIdx.x; i < npair; i += int64_t(gridDim.x) * THREADS) {
+        const int64_t row = i / ppr;
+        const int c = int(i - row * ppr) * 2;
+        bool k0, k1;
+        drop_keep2(seed, uint64_t(i), th, k0, k1);
+        out[row * cols + c] = k0 ? on : uint16_t(0);
+        if (c + 1 < cols) out[row * cols + c + 1] = k1 ? on : uint16_t(0);
     }
 }
 
@@ -403,14 +468,17 @@ extern "C" int64_t sfcvit_layernorm_bwd_ws(int M, int D) {
     return int64_t(ln_bwd_blocks(M)) * 2 * D * int64_t(sizeof(float));
 }
 
-extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const float *rstd,
-                                    const void *gamma, const void *dx_add, void *dx, float *dgamma, float *dbeta,
-                                    int M, int D, void *ws, void *stream) {
+extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, const float *rstd,
+                                         const void *gamma, const void *dx_add, void *dx, void *dx_drop, float p,
+                                         uint32_t seed, float *dgamma, float *dbeta, int M, int D, void *ws,
+                                         void *stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !ws)
         return fail(SFCVIT_EINVAL, "layernorm_bwd: null pointer");
     if (M <= 0 || D <= 0 || D % 8 || D > 2048) return fail(SFCVIT_EINVAL, "layernorm_bwd: M=%d D=%d (D %% 8 == 0, D <= 2048)", M, D);
-    if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma) || (dx_add && !aligned16(dx_add)))
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma) || (dx_add && !aligned16(dx_add)) ||
+        (dx_drop && !aligned16(dx_drop)))
         return fail(SFCVIT_EINVAL, "layernorm_bwd: alignment");
+    if (dx_drop && !(p >= 0.f && p < 1.f)) return fail(SFCVIT_EINVAL, "layernorm_bwd: dropout p=%g", p);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = ln_bwd_blocks(M);
     dim3 grid(nb), block(THREADS);
@@ -420,13 +488,20 @@ extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *
     const auto *gp = static_cast<const uint16_t *>(gamma);
     const auto *ap = static_cast<const uint16_t *>(dx_add);
     auto *dxp = static_cast<uint16_t *>(dx);
+    auto *ddp = static_cast<uint16_t *>(dx_drop);
     float *part = static_cast<float *>(ws);
-    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, part, M, D);
-    else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, part, M, D);
-    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, part, M, D);
+    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
+    else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
+    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
     if (int rc = check_launch("layernorm_bwd")) return rc;
     hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 31) / 32), dim3(256), 0, s, part, dgamma, dbeta, nb, D);
     return check_launch("layernorm_bwd_reduce");
+}
+
+extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const float *rstd,
+                                    const void *gamma, const void *dx_add, void *dx, float *dgamma, float *dbeta,
+                                    int M, int D, void *ws, void *stream) {
+    return sfcvit_layernorm_bwd_drop(dy, x, mean, rstd, gamma, dx_add, dx, nullptr, 0.f, 0u, dgamma, dbeta, M, D, ws, stream);
 }
 
 extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *stream) {
@@ -458,6 +533,37 @@ extern "C" int sfcvit_gelu_bwd(const void *dy, const void *x, void *dx, int64_t 
     hipLaunchKernelGGL(gelu_kernel<true>, dim3(grid_for(n / 8)), dim3(THREADS), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint16_t *>(dy), static_cast<const uint16_t *>(x), static_cast<uint16_t *>(dx), n / 8);
     return check_launch("gelu_bwd");
+}
+
+static int gelu_drop_check(const void *x, const void *y, int rows, int cols, float p, const char *what) {
+    if (!x || !y || rows <= 0 || cols <= 0 || cols % 8) return fail(SFCVIT_EINVAL, "%s: rows=%d cols=%d (cols %% 8 == 0)", what, rows, cols);
+    if (!(p >= 0.f && p < 1.f)) return fail(SFCVIT_EINVAL, "%s: dropout p=%g", what, p);
+    return SFCVIT_OK;
+}
+
+extern "C" int sfcvit_gelu_drop_fwd(const void *x, void *y, int rows, int cols, float p, uint32_t seed, void *stream) {
+    if (int rc = gelu_drop_check(x, y, rows, cols, p, "gelu_drop_fwd")) return rc;
+    hipLaunchKernelGGL(gelu_drop_kernel<false>, dim3(grid_for(int64_t(rows) * cols / 8)), dim3(THREADS), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint16_t *>(nullptr),
+                       static_cast<const uint16_t *>(x), static_cast<uint16_t *>(y), rows, cols, p, seed);
+    return check_launch("gelu_drop_fwd");
+}
+
+extern "C" int sfcvit_gelu_drop_bwd(const void *dy, const void *x, void *dx, int rows, int cols, float p, uint32_t seed,
+                                    void *stream) {
+    if (!dy) return fail(SFCVIT_EINVAL, "gelu_drop_bwd: null pointer");
+    if (int rc = gelu_drop_check(x, dx, rows, cols, p, "gelu_drop_bwd")) return rc;
+    hipLaunchKernelGGL(gelu_drop_kernel<true>, dim3(grid_for(int64_t(rows) * cols / 8)), dim3(THREADS), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint16_t *>(dy), static_cast<const uint16_t *>(x),
+                       static_cast<uint16_t *>(dx), rows, cols, p, seed);
+    return check_launch("gelu_drop_bwd");
+}
+
+extern "C" int sfcvit_dropout_mask(void *out, int64_t rows, int cols, float p, uint32_t seed, void *stream) {
+    if (!out || rows <= 0 || cols <= 0 || !(p >= 0.f && p < 1.f)) return fail(SFCVIT_EINVAL, "dropout_mask: bad argument");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(rows * ((cols + 1) / 2))), dim3(THREADS), 0,
+                       static_cast<hipStream_t>(stream), static_cast<uint16_t *>(out), rows, cols, p, seed);
+    return check_launch("dropout_mask");
 }
 
 extern "C" int sfcvit_soft_ce(const void *logits, const float *targets, float *loss_rows, void *dlogits, int B, int C,

@@ -28,13 +28,15 @@ class GemmArgs(ctypes.Structure):
                 ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldr", c_int32), ("ldaux", c_int32),
                 ("a_kmajor", c_int32), ("b_kmajor", c_int32), ("act", c_int32), ("dact", c_int32),
                 ("c_is_f32", c_int32), ("splitk", c_int32), ("workspace", c_void_p),
-                ("workspace_bytes", c_int64), ("force_generic", c_int32)]
+                ("workspace_bytes", c_int64), ("force_generic", c_int32),
+                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("dact_scale", c_float)]
 
 
 class AttnArgs(ctypes.Structure):
     _fields_ = [("qkv", c_void_p), ("out", c_void_p), ("lse", c_void_p), ("dout", c_void_p),
                 ("dqkv", c_void_p), ("delta", c_void_p),
-                ("B", c_int32), ("N", c_int32), ("H", c_int32), ("hd", c_int32), ("scale", c_float)]
+                ("B", c_int32), ("N", c_int32), ("H", c_int32), ("hd", c_int32), ("scale", c_float),
+                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32)]
 
 
 class AdamWArgs(ctypes.Structure):
@@ -63,7 +65,13 @@ SIGNATURES = {
                                      c_int, c_int, c_float, c_void_p]),
     "sfcvit_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "sfcvit_layernorm_bwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_float, ctypes.c_uint32, c_void_p, c_void_p,
+                                          c_int, c_int, c_void_p, c_void_p]),
     "sfcvit_layernorm_bwd_ws": (c_int64, [c_int, c_int]),
+    "sfcvit_gelu_drop_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p]),
+    "sfcvit_gelu_drop_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p]),
+    "sfcvit_dropout_mask": (c_int, [c_void_p, c_int64, c_int, c_float, ctypes.c_uint32, c_void_p]),
     "sfcvit_attention_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "sfcvit_attention_bwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "sfcvit_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

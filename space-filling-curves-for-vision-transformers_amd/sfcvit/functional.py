@@ -160,24 +160,27 @@ def mixer_block(x, ln_w, ln_b, w1, b1, w2, b2, eps=1e-5):
 
 # ----------------------------------------------------------------------------
 class _EncoderLayer(Function):
-    """Post-norm transformer encoder layer, dropout off:
-         a  = out_proj(attention(in_proj(x)));  x1 = LN1(x + a)
-         f  = W2 relu(W1 x1 + b1) + b2;         y  = LN2(x1 + f)"""
+    """Post-norm transformer encoder layer (torch:nn/modules/transformer.py:951-982):
+         a  = out_proj(attention(in_proj(x)));  x1 = LN1(x + drop1(a))
+         f  = W2 drop(relu(W1 x1 + b1)) + b2;   y  = LN2(x1 + drop2(f))
+    with dropout p on the attention probabilities as well.  p = 0 (eval) makes every mask the
+    identity.  Masks are functions of (seed, element index), regenerated in backward."""
 
     @staticmethod
-    def forward(ctx, x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps):
+    def forward(ctx, x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps, p, seeds):
         B, N, D = x.shape
+        sa, s1_, sf, s2_ = seeds
         x2 = _c(x).view(B * N, D)
         qkv = ops.gemm(x2, in_w, bias=in_b)
-        o, lse = ops.attention_fwd(qkv.view(B, N, 3 * D), n_heads)
-        s1 = ops.gemm(o.view(B * N, D), out_w, bias=out_b, residual=x2)
+        o, lse = ops.attention_fwd(qkv.view(B, N, 3 * D), n_heads, p, sa)
+        s1 = ops.gemm(o.view(B * N, D), out_w, bias=out_b, residual=x2, dropout_p=p, dropout_seed=s1_)
         x1, mean1, rstd1 = ops.layernorm_fwd(s1, n1_w, n1_b, eps)
-        h = ops.gemm(x1, w1, bias=b1, act=ops.ACT_RELU)
-        s2 = ops.gemm(h, w2, bias=b2, residual=x1)
+        h = ops.gemm(x1, w1, bias=b1, act=ops.ACT_RELU, dropout_p=p, dropout_seed=sf)
+        s2 = ops.gemm(h, w2, bias=b2, residual=x1, dropout_p=p, dropout_seed=s2_)
         y, mean2, rstd2 = ops.layernorm_fwd(s2, n2_w, n2_b, eps)
         ctx.save_for_backward(x2, qkv, o, lse, s1, mean1, rstd1, x1, h, s2, mean2, rstd2,
                               in_w, out_w, n1_w, w1, w2, n2_w)
-        ctx.n_heads, ctx.shape = n_heads, (B, N, D)
+        ctx.n_heads, ctx.shape, ctx.p, ctx.seeds = n_heads, (B, N, D), p, seeds
         return y.view(B, N, D)
 
     @staticmethod
@@ -185,26 +188,40 @@ class _EncoderLayer(Function):
         (x2, qkv, o, lse, s1, mean1, rstd1, x1, h, s2, mean2, rstd2,
          in_w, out_w, n1_w, w1, w2, n2_w) = ctx.saved_tensors
         B, N, D = ctx.shape
+        p = ctx.p
+        sa, s1_, sf, s2_ = ctx.seeds
         dy2 = _c(dy).view(B * N, D)
-        ds2, dg2, dbt2 = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w)
-        dw2, db2 = _wgrad(ds2, h), _bgrad(ds2)
-        dh = ops.gemm(ds2, w2, b_kmajor=True, aux_in=h, dact=ops.ACT_RELU)
+        if p > 0:
+            ds2, dg2, dbt2, df = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w, drop_p=p, drop_seed=s2_)
+        else:
+            ds2, dg2, dbt2 = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w)
+            df = ds2
+        dw2, db2 = _wgrad(df, h), _bgrad(df)
+        # h is stored after relu + dropout: (h > 0) is the joint mask, 1/(1-p) the dropout scale
+        dh = ops.gemm(df, w2, b_kmajor=True, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p))
         dw1, db1 = _wgrad(dh, x1), _bgrad(dh)
         dx1 = ops.gemm(dh, w1, b_kmajor=True, residual=ds2)
-        ds1, dg1, dbt1 = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w)
+        if p > 0:
+            ds1, dg1, dbt1, da = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w, drop_p=p, drop_seed=s1_)
+        else:
+            ds1, dg1, dbt1 = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w)
+            da = ds1
         o2 = o.view(B * N, D)
-        dwo, dbo = _wgrad(ds1, o2), _bgrad(ds1)
-        do = ops.gemm(ds1, out_w, b_kmajor=True)
-        dqkv = ops.attention_bwd(qkv.view(B, N, 3 * D), o, lse, do.view(B, N, D), ctx.n_heads).view(B * N, 3 * D)
+        dwo, dbo = _wgrad(da, o2), _bgrad(da)
+        do = ops.gemm(da, out_w, b_kmajor=True)
+        dqkv = ops.attention_bwd(qkv.view(B, N, 3 * D), o, lse, do.view(B, N, D), ctx.n_heads, p, sa).view(B * N, 3 * D)
         dwi, dbi = _wgrad(dqkv, x2), _bgrad(dqkv)
         dx = ops.gemm(dqkv, in_w, b_kmajor=True, residual=ds1)
         return (dx.view(B, N, D), dwi, dbi, dwo, dbo, dg1.to(_BF16), dbt1.to(_BF16), dw1, db1, dw2, db2,
-                dg2.to(_BF16), dbt2.to(_BF16), None, None)
+                dg2.to(_BF16), dbt2.to(_BF16), None, None, None, None)
 
 
-def encoder_layer(x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps=1e-5):
+def encoder_layer(x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps=1e-5,
+                  dropout_p=0.0):
+    """dropout_p > 0 = training-mode nn.TransformerEncoderLayer (fresh masks every call)."""
     args = [_bf(t) for t in (x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b)]
-    return _EncoderLayer.apply(*args, n_heads, eps)
+    seeds = tuple(ops.next_seed() for _ in range(4)) if dropout_p > 0 else (0, 0, 0, 0)
+    return _EncoderLayer.apply(*args, n_heads, eps, float(dropout_p), seeds)
 
 
 # ----------------------------------------------------------------------------
@@ -217,24 +234,25 @@ def _pad_rows(t, rows):
 
 
 class _Head(Function):
-    """LN -> h = z W_emb^T -> y = <h, W_seq> -> GELU -> classifier (Dropout off).
+    """LN -> h = z W_emb^T -> y = <h, W_seq> -> GELU -> Dropout(p) -> classifier.
     The classifier is computed on a class count padded to a multiple of 8 (16-byte rows)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w_emb, w_seq, wc, bc, eps):
+    def forward(ctx, x, ln_w, ln_b, w_emb, w_seq, wc, bc, eps, p, seed):
         B, N, D = x.shape
         R, O, C = w_emb.shape[0], w_seq.shape[0], wc.shape[0]
         x2 = _c(x).view(B * N, D)
         z, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
         h = ops.gemm(z, w_emb)                                      # [B*N, R]
         y1 = ops.gemm(h.view(B, N * R), w_seq.view(O, N * R))      # [B, O]
-        a = ops.gelu_fwd(y1)
+        a = ops.gelu_drop_fwd(y1, p, seed) if p > 0 else ops.gelu_fwd(y1)
         cpad = (C + 7) // 8 * 8
         wc_p, bc_p = _pad_rows(wc, cpad), _pad_rows(bc, cpad)
         logits = ops.gemm(a, wc_p, bias=bc_p)                       # [B, cpad]
         ctx.save_for_backward(x2, mean, rstd, z, h, y1, a, ln_w, w_emb, w_seq, wc_p)
         ctx.dims = (B, N, D, R, O, C, cpad)
-        return logits[:, :C]
+        ctx.p, ctx.seed = p, seed
+        return logits[:, :C] if cpad != C else logits
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -245,18 +263,20 @@ class _Head(Function):
         dwc = ops.gemm(dl, a, a_kmajor=True, b_kmajor=True)[:C]
         dbc = ops.colsum(dl)[:C].to(_BF16)
         da = ops.gemm(dl, wc_p, b_kmajor=True)                      # [B, O]
-        dy1 = ops.gelu_bwd(da, y1)
+        dy1 = ops.gelu_drop_bwd(da, y1, ctx.p, ctx.seed) if ctx.p > 0 else ops.gelu_bwd(da, y1)
         h2 = h.view(B, N * R)
         dwseq = ops.gemm(dy1, h2, a_kmajor=True, b_kmajor=True).view(O, N, R)
         dh = ops.gemm(dy1, w_seq.view(O, N * R), b_kmajor=True).view(B * N, R)
         dwemb = _wgrad(dh, z)
         dz = ops.gemm(dh, w_emb, b_kmajor=True)
         dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w)
-        return dx.view(B, N, D), dg.to(_BF16), dbeta.to(_BF16), dwemb, dwseq, dwc, dbc, None
+        return dx.view(B, N, D), dg.to(_BF16), dbeta.to(_BF16), dwemb, dwseq, dwc, dbc, None, None, None
 
 
-def predictor_head(x, ln_w, ln_b, w_emb, w_seq, wc, bc, eps=1e-5):
-    return _Head.apply(_bf(x), _bf(ln_w), _bf(ln_b), _bf(w_emb), _c(_bf(w_seq)), _bf(wc), _bf(bc), eps)
+def predictor_head(x, ln_w, ln_b, w_emb, w_seq, wc, bc, eps=1e-5, dropout_p=0.0):
+    seed = ops.next_seed() if dropout_p > 0 else 0
+    return _Head.apply(_bf(x), _bf(ln_w), _bf(ln_b), _bf(w_emb), _c(_bf(w_seq)), _bf(wc), _bf(bc), eps,
+                       float(dropout_p), seed)
 
 
 # ----------------------------------------------------------------------------

@@ -17,13 +17,6 @@ from .. import functional as F
 from ..tokenizers.base_patch_embedding import BasePatchEmbedding
 
 
-def _no_dropout_yet(module, p):
-    if module.training and p > 0:
-        raise NotImplementedError(
-            "training-mode dropout is not wired into the HIP kernels yet: construct with dropout_p=0 "
-            "or call .eval()")
-
-
 class TransformerSeqEncoder(nn.Module):
     """vit.py:177-242: `depth` post-norm nn.TransformerEncoderLayer (relu, eps 1e-5)."""
 
@@ -41,13 +34,13 @@ class TransformerSeqEncoder(nn.Module):
         self.to_patch_embedding = method
 
     def forward(self, x):
-        _no_dropout_yet(self, self.dropout_p)
+        p = self.dropout_p if self.training else 0.0
         for layer in self.transformer.layers:
             a = layer.self_attn
             x = F.encoder_layer(x, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
                                 layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,
                                 layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias,
-                                self.n_head, layer.norm1.eps)
+                                self.n_head, layer.norm1.eps, dropout_p=p)
         return x
 
 
@@ -108,10 +101,14 @@ class MultiLayerPredictor(nn.Sequential):
         self._dropout_p = dropout_p
 
     def forward(self, x):
-        _no_dropout_yet(self, self._dropout_p)
+        p = self._dropout_p if self.training else 0.0
         if self._n_layers == 2:
             ln, fact, fc = self[0], self[1], self[4]
-            return F.predictor_head(x, ln.weight, ln.bias, fact.W_emb, fact.W_seq, fc.weight, fc.bias, ln.eps)
+            return F.predictor_head(x, ln.weight, ln.bias, fact.W_emb, fact.W_seq, fc.weight, fc.bias, ln.eps,
+                                    dropout_p=p)
+        if p > 0:
+            raise NotImplementedError("training-mode dropout of MultiLayerPredictor is fused only for n_layers == 2 "
+                                      "(the form VisionTransformer{,1D} build)")
         for m in self:
             if isinstance(m, nn.LayerNorm):
                 x = F.layer_norm(x, m.weight, m.bias, m.eps)
@@ -120,7 +117,7 @@ class MultiLayerPredictor(nn.Sequential):
             elif isinstance(m, nn.GELU):
                 x = F.gelu(x)
             elif isinstance(m, nn.Dropout):
-                pass                      # eval / p = 0 (checked above)
+                pass                      # p = 0 here (checked above)
             else:
                 x = m(x)
         return x

@@ -95,8 +95,15 @@ def auto_splitk(M, N, K):
     return max(1, min((768 + tiles - 1) // tiles, K // 512))
 
 
+def next_seed():
+    """32-bit dropout seed drawn on the host from torch's default CPU generator: reproducible under
+    torch.manual_seed, no device synchronisation (kernels receive it as a plain argument)."""
+    return int(torch.randint(0, 0x7FFFFFFF, (), dtype=torch.int64)) * 2 + 1
+
+
 def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, residual=None,
-         aux_in=None, dact=ACT_NONE, want_aux=False, out_f32=False, splitk=None, force_generic=False):
+         aux_in=None, dact=ACT_NONE, want_aux=False, out_f32=False, splitk=None, force_generic=False,
+         dropout_p=0.0, dropout_seed=0, dact_scale=1.0):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  a: [M,K] (or [K,M] if a_kmajor),
     b: [N,K] (or [K,N] if b_kmajor), bf16.  Returns C (and the pre-activation if want_aux)."""
     _rows2d(a, _BF16, "gemm a")
@@ -124,7 +131,9 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
     args.ldaux = ldaux
     args.a_kmajor, args.b_kmajor = int(a_kmajor), int(b_kmajor)
     args.act, args.dact, args.c_is_f32 = act, dact, int(out_f32)
-    plain = bias is None and residual is None and aux_in is None and not want_aux and act == 0 and dact == 0
+    args.dropout_p, args.dropout_seed, args.dact_scale = dropout_p, dropout_seed, dact_scale
+    plain = (bias is None and residual is None and aux_in is None and not want_aux and act == 0 and dact == 0
+             and dropout_p == 0.0)
     if splitk is None:
         splitk = auto_splitk(M, N, K) if plain else 1
     ws = None
@@ -160,25 +169,28 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0):
+    """-> dx, dgamma, dbeta (and dx_drop = dropout-masked dx when drop_p > 0, as 4th value)."""
     _need(dy, _BF16, "layernorm dy", 2)
     _need(x, _BF16, "layernorm x", 2)
     M, D = x.shape
     dx = torch.empty_like(x)
+    dx_drop = torch.empty_like(x) if drop_p > 0 else None
     dg = torch.empty(D, device=x.device, dtype=torch.float32)
     db = torch.empty(D, device=x.device, dtype=torch.float32)
     ws = torch.empty(lib.sfcvit_layernorm_bwd_ws(M, D), device=x.device, dtype=torch.uint8)
     if dx_add is not None:
         _need(dx_add, _BF16, "layernorm dx_add", 2)
-    check(lib.sfcvit_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_add), _p(dx), _p(dg), _p(db),
-                                   M, D, _p(ws), _stream()), "sfcvit_layernorm_bwd")
-    return dx, dg, db
+    check(lib.sfcvit_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_add), _p(dx), _p(dx_drop),
+                                        drop_p, drop_seed, _p(dg), _p(db), M, D, _p(ws), _stream()),
+          "sfcvit_layernorm_bwd")
+    return (dx, dg, db, dx_drop) if drop_p > 0 else (dx, dg, db)
 
 
 # ----------------------------------------------------------------------------
 # attention
 # ----------------------------------------------------------------------------
-def attention_fwd(qkv, n_heads):
+def attention_fwd(qkv, n_heads, dropout_p=0.0, dropout_seed=0):
     """qkv [B, N, 3*D] bf16 -> out [B, N, D] bf16, lse [B, H, N] fp32."""
     _need(qkv, _BF16, "attention qkv", 3)
     B, N, D3 = qkv.shape
@@ -189,12 +201,13 @@ def attention_fwd(qkv, n_heads):
     a = _lib.AttnArgs()
     a.qkv, a.out, a.lse = qkv.data_ptr(), out.data_ptr(), lse.data_ptr()
     a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
+    a.dropout_p, a.dropout_seed = dropout_p, dropout_seed
     check(_launch("attn_fwd_kernel", 4.0 * B * n_heads * N * N * hd,
                   lambda: lib.sfcvit_attention_fwd(ctypes.byref(a), _stream())), "sfcvit_attention_fwd")
     return out, lse
 
 
-def attention_bwd(qkv, out, lse, dout, n_heads):
+def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0):
     _need(dout, _BF16, "attention dout", 3)
     B, N, D3 = qkv.shape
     D = D3 // 3
@@ -205,6 +218,7 @@ def attention_bwd(qkv, out, lse, dout, n_heads):
     a.qkv, a.out, a.lse, a.dout = qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr()
     a.dqkv, a.delta = dqkv.data_ptr(), delta.data_ptr()
     a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
+    a.dropout_p, a.dropout_seed = dropout_p, dropout_seed
     check(_launch("attn_bwd", 10.0 * B * n_heads * N * N * hd,
                   lambda: lib.sfcvit_attention_bwd(ctypes.byref(a), _stream())), "sfcvit_attention_bwd")
     return dqkv
@@ -275,6 +289,28 @@ def gelu_bwd(dy, x):
     dx = torch.empty_like(x)
     check(lib.sfcvit_gelu_bwd(_p(dy), _p(x), _p(dx), x.numel(), _stream()), "sfcvit_gelu_bwd")
     return dx
+
+
+def gelu_drop_fwd(x, p, seed):
+    _need(x, _BF16, "gelu_drop x", 2)
+    y = torch.empty_like(x)
+    check(lib.sfcvit_gelu_drop_fwd(_p(x), _p(y), x.shape[0], x.shape[1], p, seed, _stream()), "sfcvit_gelu_drop_fwd")
+    return y
+
+
+def gelu_drop_bwd(dy, x, p, seed):
+    _need(x, _BF16, "gelu_drop x", 2)
+    _need(dy, _BF16, "gelu_drop dy", 2)
+    dx = torch.empty_like(x)
+    check(lib.sfcvit_gelu_drop_bwd(_p(dy), _p(x), _p(dx), x.shape[0], x.shape[1], p, seed, _stream()), "sfcvit_gelu_drop_bwd")
+    return dx
+
+
+def dropout_mask(rows, cols, p, seed, device="cuda"):
+    """The keep mask as bf16 {0, 1/(1-p)} [rows, cols] (tests / debugging)."""
+    out = torch.empty((rows, cols), device=device, dtype=_BF16)
+    check(lib.sfcvit_dropout_mask(_p(out), rows, cols, p, seed, _stream()), "sfcvit_dropout_mask")
+    return out
 
 
 def soft_ce(logits, targets, n_classes, gscale):

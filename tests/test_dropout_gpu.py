@@ -1,0 +1,183 @@
+"""Training-mode dropout (nn.TransformerEncoderLayer's four sites, MultiLayerPredictor's Dropout(0.5))
+fused into the HIP kernels.  Masks are a function of (seed, element index), so the tests materialise
+the same masks with sfcvit_dropout_mask and compare against fp32 torch math using them."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sfcvit import ops as o
+    return o
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def close(got, ref, rel=1.0 / 64, abs_scale=1.0 / 48):
+    got, ref = got.float(), ref.float()
+    tol = rel * ref.abs() + abs_scale * ref.pow(2).mean().sqrt().clamp_min(1e-6)
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())}/{bad.numel()} off, max err {float((got - ref).abs().max())}"
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_mask_statistics(ops, p):
+    m = ops.dropout_mask(4096, 770, p, seed=1234).float()
+    vals = torch.unique(m)
+    assert vals.numel() == 2 and vals[0] == 0 and abs(float(vals[1]) - 1 / (1 - p)) < 1e-2
+    keep = float((m > 0).float().mean())
+    assert abs(keep - (1 - p)) < 2e-3
+    # different seeds and neighbouring rows / columns are uncorrelated
+    m2 = ops.dropout_mask(4096, 770, p, seed=1235).float()
+    agree = float(((m > 0) == (m2 > 0)).float().mean())
+    assert abs(agree - (p * p + (1 - p) ** 2)) < 5e-3
+    k = (m > 0).float()
+    for a, b in ((k[:, :-1], k[:, 1:]), (k[:-1], k[1:])):
+        cov = float((a * b).mean() - a.mean() * b.mean())
+        assert abs(cov) < 2e-3
+
+
+def test_gemm_dropout_epilogue(ops):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, N, K, p, seed = 512, 384, 256, 0.1, 77
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K))
+    bias = bf(torch.randn(N, device="cuda", generator=g))
+    res = bf(torch.randn(M, N, device="cuda", generator=g))
+    mask = ops.dropout_mask(M, N, p, seed).float()
+    z = torch.relu(a.float() @ w.float().t() + bias.float())
+    for force in (1, 4):                      # generic and large-tile kernels share the epilogue
+        y = ops.gemm(a, w, bias=bias, act=ops.ACT_RELU, residual=res, dropout_p=p, dropout_seed=seed, force_generic=force)
+        close(y, z * mask + res.float())
+    # the (h > 0) mask of the stored output reproduces relu-mask AND dropout-mask in backward
+    h = ops.gemm(a, w, bias=bias, act=ops.ACT_RELU, dropout_p=p, dropout_seed=seed)
+    assert torch.equal(h > 0, (bf(z) > 0) & (mask > 0))
+
+
+def test_layernorm_bwd_dropped_output(ops):
+    g = torch.Generator(device="cuda").manual_seed(2)
+    M, D, p, seed = 777, 768, 0.1, 5
+    x = bf(torch.randn(M, D, device="cuda", generator=g))
+    dy = bf(torch.randn(M, D, device="cuda", generator=g))
+    gamma = bf(1 + 0.1 * torch.randn(D, device="cuda", generator=g))
+    beta = bf(torch.zeros(D, device="cuda"))
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gamma)
+    dx2, dg2, db2, dxd = ops.layernorm_bwd(dy, x, mean, rstd, gamma, drop_p=p, drop_seed=seed)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    mask = ops.dropout_mask(M, D, p, seed).float()
+    close(dxd, dx.float() * mask, rel=1 / 100, abs_scale=1e-3)
+    assert torch.equal(dxd == 0, (mask == 0) | (dx == 0))
+
+
+def test_gelu_dropout(ops):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = bf(torch.randn(256, 1536, device="cuda", generator=g))
+    dy = bf(torch.randn(256, 1536, device="cuda", generator=g))
+    mask = ops.dropout_mask(256, 1536, 0.5, 9).float()
+    close(ops.gelu_drop_fwd(x, 0.5, 9), ops.gelu_fwd(x).float() * mask, rel=1 / 100, abs_scale=1e-3)
+    close(ops.gelu_drop_bwd(dy, x, 0.5, 9), ops.gelu_bwd(dy, x).float() * mask, rel=1 / 100, abs_scale=1e-3)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 196, 2), (1, 70, 3), (2, 4, 1)])
+def test_attention_dropout(ops, B, N, H):
+    g = torch.Generator(device="cuda").manual_seed(4)
+    p, seed, hd = 0.1, 4242, 64
+    D = H * hd
+    qkv = bf(torch.randn(B, N, 3 * D, device="cuda", generator=g))
+    dout = bf(torch.randn(B, N, D, device="cuda", generator=g))
+    mask = ops.dropout_mask(B * H * N, N, p, seed).float().view(B, H, N, N)
+    qf = qkv.float().requires_grad_(True)
+    q, k, v = qf.split(D, dim=-1)
+    sp = lambda t: t.reshape(B, N, H, hd).transpose(1, 2)
+    s = (sp(q) @ sp(k).transpose(-1, -2)) / math.sqrt(hd)
+    ref = ((torch.softmax(s, -1) * mask) @ sp(v)).transpose(1, 2).reshape(B, N, D)
+    ref.backward(dout.float())
+    out, lse = ops.attention_fwd(qkv, H, p, seed)
+    close(out, ref.detach())
+    assert torch.allclose(lse, torch.logsumexp(s.detach(), -1), atol=2e-2, rtol=1e-2)   # normaliser is un-dropped
+    dqkv = ops.attention_bwd(qkv, out, lse, dout, H, p, seed)
+    close(dqkv, qf.grad, rel=1 / 48, abs_scale=1 / 24)
+
+
+def test_encoder_layer_training_mode_against_masked_reference(ops):
+    import sfcvit.functional as F
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, N, D, H, Fd, p = 2, 68, 128, 2, 256, 0.1
+    seeds = (11, 22, 33, 44)
+    r = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc)
+    x = bf(r(B, N, D))
+    P = dict(in_w=bf(r(3 * D, D, sc=D ** -0.5)), in_b=bf(r(3 * D, sc=0.1)), out_w=bf(r(D, D, sc=D ** -0.5)),
+             out_b=bf(r(D, sc=0.1)), n1_w=bf(1 + r(D, sc=0.1)), n1_b=bf(r(D, sc=0.1)),
+             w1=bf(r(Fd, D, sc=D ** -0.5)), b1=bf(r(Fd, sc=0.1)), w2=bf(r(D, Fd, sc=Fd ** -0.5)), b2=bf(r(D, sc=0.1)),
+             n2_w=bf(1 + r(D, sc=0.1)), n2_b=bf(r(D, sc=0.1)))
+    dy = bf(r(B, N, D))
+    order = ["in_w", "in_b", "out_w", "out_b", "n1_w", "n1_b", "w1", "b1", "w2", "b2", "n2_w", "n2_b"]
+    leaves = [x.clone().requires_grad_(True)] + [P[k].clone().requires_grad_(True) for k in order]
+    y = F._EncoderLayer.apply(*leaves, H, 1e-5, p, seeds)
+    y.backward(dy)
+
+    # fp32 reference with the same masks
+    M = B * N
+    ma = ops.dropout_mask(B * H * N, N, p, seeds[0]).float().view(B, H, N, N)
+    m1 = ops.dropout_mask(M, D, p, seeds[1]).float().view(B, N, D)
+    mf = ops.dropout_mask(M, Fd, p, seeds[2]).float().view(B, N, Fd)
+    m2 = ops.dropout_mask(M, D, p, seeds[3]).float().view(B, N, D)
+    xr = x.float().requires_grad_(True)
+    R = {k: v.float().requires_grad_(True) for k, v in P.items()}
+    hd = D // H
+    qkv = xr @ R["in_w"].t() + R["in_b"]
+    q, k, v = qkv.split(D, dim=-1)
+    sp = lambda t: t.reshape(B, N, H, hd).transpose(1, 2)
+    s = (sp(q) @ sp(k).transpose(-1, -2)) / math.sqrt(hd)
+    o = ((torch.softmax(s, -1) * ma) @ sp(v)).transpose(1, 2).reshape(B, N, D)
+    a = (o @ R["out_w"].t() + R["out_b"]) * m1
+    x1 = torch.nn.functional.layer_norm(xr + a, (D,), R["n1_w"], R["n1_b"])
+    hh = torch.relu(x1 @ R["w1"].t() + R["b1"]) * mf
+    f = (hh @ R["w2"].t() + R["b2"]) * m2
+    yr = torch.nn.functional.layer_norm(x1 + f, (D,), R["n2_w"], R["n2_b"])
+    yr.backward(dy.float())
+    close(y, yr.detach(), rel=1 / 32, abs_scale=1 / 24)
+    refs = [xr] + [R[k] for k in order]
+    for name, got, ref in zip(["x"] + order, leaves, refs):
+        gg, rr = got.grad.float().flatten(), ref.grad.flatten()
+        cos = float(torch.dot(gg, rr) / (gg.norm() * rr.norm() + 1e-30))
+        assert cos > 0.99, (name, cos)
+        assert abs(float(gg.norm() / rr.norm()) - 1) < 5e-2, name
+
+
+def test_model_train_vs_eval_modes():
+    from oracle.cases import MODEL_CASES
+    from oracle import formula, vit_oracle
+    from test_host_cpu import build_model
+    import sfcvit.functional as F
+    cfg, batch = MODEL_CASES["hilbert32_1d"]
+    model = build_model(cfg)
+    model.load_state_dict(vit_oracle.formula_state(cfg))
+    model = model.to("cuda", dtype=torch.bfloat16)
+    x = formula.image_batch(batch, cfg.in_channels, cfg.img_size, cfg.img_size).cuda()
+    tgt = formula.soft_targets(batch, cfg.num_classes).cuda()
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(x), model(x)
+    assert torch.equal(e1, e2)
+    model.train()                                  # reference defaults: p = 0.1 in the encoder, 0.5 in the head
+    torch.manual_seed(123)
+    t1 = model(x)
+    t2 = model(x)
+    assert not torch.equal(t1, t2)                 # fresh masks every call
+    torch.manual_seed(123)
+    t3 = model(x)
+    assert torch.equal(t1, t3)                     # reproducible under torch.manual_seed
+    assert not torch.equal(t1, e1)
+    loss = F.soft_target_cross_entropy(t3, tgt)
+    loss.backward()
+    for k, prm in model.named_parameters():
+        if not k.startswith("mlp_mixer.token_mix"):
+            assert prm.grad is not None and torch.isfinite(prm.grad.float()).all(), k
