@@ -168,7 +168,7 @@ def main():
             "final_loss": round(loss_v, 4),
         }
         if kern:
-            gemm_keys = [k for k in kern if k.startswith("gemm_kernel")]
+            gemm_keys = [k for k in kern if k.startswith("gemm ")]
             dom = max(kern, key=lambda k: kern[k]["ms_total"])
             r = kern[dom]
             ach = r["work_total"] / (r["ms_total"] * 1e-3) / 1e12

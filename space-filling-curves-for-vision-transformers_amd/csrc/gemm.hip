@@ -22,7 +22,7 @@ namespace {
 
 using namespace gemm_core;
 
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, bool HEAVY>
 __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const sfcvit_gemm_args g, int k_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,20 +67,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const sfcvit_gemm_args
         return;
     }
 
-    // Epilogue (N % 4 == 0 is checked on the host: a 4-vector is entirely inside or outside).
-    const uint16_t *bias = static_cast<const uint16_t *>(g.bias);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-        if (n >= g.N) continue;
-        float bv[4];
-        load_bias4(bias, n, bv);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-            if (m < g.M) epilogue4(g, m, n, acc[i][j], bv);
-        }
-    }
+    // Epilogue through LDS (operand tiles are dead after the loop's final barrier).
+    epilogue_tile<4, 4, HEAVY>(g, acc, reinterpret_cast<float *>(smem) + wave * (32 * 68), m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // C[m, n] = sum_z slab[z][m][n]; 4 columns per thread.
@@ -148,11 +136,18 @@ extern "C" int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream) {
     if (big > 0) return big;
     dim3 grid(((a->N + BN - 1) / BN) * ((a->M + BM - 1) / BM), 1, splits), block(THREADS);
     const size_t lds = 4 * TILE_BYTES;
+    const bool heavy = a->act == SFCVIT_ACT_GELU || a->dact == SFCVIT_ACT_GELU;
+#define SFCVIT_GO(AK, BK)                                                                                   \
+    do {                                                                                                    \
+        if (heavy) hipLaunchKernelGGL((gemm_kernel<AK, BK, true>), grid, block, lds, s, *a, k_per_split);   \
+        else hipLaunchKernelGGL((gemm_kernel<AK, BK, false>), grid, block, lds, s, *a, k_per_split);        \
+    } while (0)
     if (big == 0) {
-    } else if (!a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, s, *a, k_per_split);
-    else if (!a->a_kmajor && a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, lds, s, *a, k_per_split);
-    else if (a->a_kmajor && !a->b_kmajor) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, lds, s, *a, k_per_split);
-    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, lds, s, *a, k_per_split);
+    } else if (!a->a_kmajor && !a->b_kmajor) SFCVIT_GO(false, false);
+    else if (!a->a_kmajor && a->b_kmajor) SFCVIT_GO(false, true);
+    else if (a->a_kmajor && !a->b_kmajor) SFCVIT_GO(true, false);
+    else SFCVIT_GO(true, true);
+#undef SFCVIT_GO
     if (int rc = check_launch("gemm")) return rc;
     if (splits > 1) {
         const int64_t nvec = int64_t(a->M) * (a->N / 4);

@@ -1,20 +1,27 @@
-// Large-tile bf16 MFMA GEMM for gfx950: 256 x BN x 64 tiles (BN = 256 or 128), 8 waves,
-// operands staged HBM -> LDS directly with global_load_lds_dwordx4 (LDS-DMA: no staging
-// registers, no ds_write pass), two LDS buffers, the DMA of k-tile t+1 in flight under the
-// MFMAs of k-tile t.  Used by sfcvit_gemm whenever M % 256 == 0, N % BN == 0 and the k range
-// of a workgroup is a multiple of 64 -- every large GEMM of ViT-B/L at the benchmark batch --
-// and the generic 128 x 128 kernel (gemm.hip) takes everything else.
+// Large-tile bf16 MFMA GEMM for gfx950: 256 x BN x 32 stages (BN = 256 or 128), 8 waves.
+// Used by sfcvit_gemm whenever M % 256 == 0, N % BN == 0 and the k range of a workgroup is a
+// multiple of 32 -- every large GEMM of ViT-B/L at the benchmark batch; the generic 128 x 128
+// kernel (gemm.hip) takes everything else.
 //
-// Why 256-wide tiles: at 128 x 128 x 64 a workgroup moves 32 KB per 2.1 MFLOP, i.e. 64 B/clk/CU
-// at full MFMA rate, more than an XCD's L2 delivers per CU; 256 x 256 halves the bytes per flop.
+// Why 256-wide tiles: at 128 x 128 a workgroup moves 32 KB per 2.1 MFLOP, i.e. 64 B/clk/CU at
+// full MFMA rate, more than an XCD's L2 delivers per CU; 256 x 256 halves the bytes per flop.
 //
-// LDS-DMA writes are lane-linear (wave-uniform base + lane * 16 B), so the bank-conflict
-// swizzles of the "kc" / "st" images (device_common.h) are applied to the per-lane SOURCE
-// address while the LDS destination stays linear; fragment reads use the same swizzle
-// (cdna_hip_programming.md §5.4 rule 21).
+// Structure (measured motivation in DESIGN.md §5):
+//  * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+//    ds_write pass) into a 4-slot ring of 32-deep stages (4 x 32 KiB).  The DMA of stage s+4 is
+//    issued as soon as stage s has been read, so 2-3 stages (64-96 KB per CU) are in flight
+//    across barriers: one batch in flight drained every k-tile was memory-latency bound
+//    (tools/gemm_lab/dma_probe.hip: 61 -> 85 GB/s per CU with two in flight).
+//  * counted waits only: `s_waitcnt vmcnt(2 stages)` + a raw s_barrier once per stage, placed in
+//    the MIDDLE of the stage's 32 MFMAs; the fragments of stage s+1 are then read from LDS into a
+//    second register set while the second half of stage s's MFMAs runs, so no MFMA waits on LDS.
+//  * LDS-DMA writes are lane-linear (wave-uniform base + lane * 16 B), so the bank-conflict
+//    swizzles of the LDS images are applied to the per-lane SOURCE address and again on the
+//    fragment reads (cdna_hip_programming.md §5.4 rule 21).  Images: "kc32" [rows][32 k], 64-B
+//    rows, 16-B chunk ^ 2*bit2(row) (ds_read_b128, conflict-free); "st" [32 k][128 cols]
+//    sub-images as in device_common.h (ds_read_b64_tr_b16).
 //
 //   waves: 2 (M) x 4 (N); wave tile 128 x BN/4 = 8 x (BN/64) fragments of 16x16x32
-//   LDS:   2 buffers x (A 32 KiB + B BN*128 B)  = 128 KiB (BN=256) / 96 KiB (BN=128)
 #include "common_host.h"
 #include "gemm_core.h"
 
@@ -23,26 +30,40 @@ namespace {
 
 using namespace gemm_core;
 
-constexpr int T256 = 512;                 // threads
-constexpr int A_BYTES = 256 * 64 * 2;     // 32 KiB
+constexpr int A_STAGE = 256 * 32 * 2;     // 16 KiB
+// Two configurations:
+//   BN = 256: 8 waves (2 x 4), ring of 4 x 32 KiB = 128 KiB, one workgroup per CU
+//   BN = 128: 4 waves (2 x 2), ring of 3 x 24 KiB =  72 KiB, TWO workgroups per CU, so that one
+//             workgroup's epilogue (30 % of a K = 768 tile) overlaps the other's k-loop
+// Every wave owns a 128 x 64 tile (8 x 4 fragments) in both.
+template <int BN_> struct Cfg {
+    static constexpr int WN = BN_ / 64;              // waves along N
+    static constexpr int T = 128 * WN;               // threads
+    static constexpr int NSLOT = BN_ == 256 ? 4 : 3;
+    static constexpr int STAGE = A_STAGE + BN_ * 32 * 2;
+    static constexpr int G = (256 + BN_) * 4 / T;    // LDS-DMA instructions per thread per stage
+    static constexpr int LDS = NSLOT * STAGE;
+};
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-// Issue the LDS-DMA of one operand tile: ROWS x 64 (k-contiguous, "kc" image) or
-// 64 x ROWS (k-major; ROWS/128 "st" sub-images of 64 x 128).  ROWS * 8 16-byte slots,
-// slot p = i * 512 + tid lands at LDS byte p * 16.
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void dma_tile(char *img, const uint16_t *__restrict__ src, int ld, int row0, int k0, int tid) {
+__device__ __forceinline__ int kc32_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 2) & 1) << 1)) << 4); }
+
+// Issue the LDS-DMA of one operand stage: ROWS x 32 (k-contiguous, "kc32" image) or 32 x ROWS
+// (k-major; ROWS/128 "st" sub-images of 32 x 128).  ROWS * 4 16-byte slots, slot p = i*512 + tid
+// lands at LDS byte p * 16.
+template <bool KMAJOR, int ROWS, int T>
+__device__ __forceinline__ void dma_stage(char *img, const uint16_t *__restrict__ src, int ld, int row0, int k0, int tid) {
 #pragma unroll
-    for (int i = 0; i < ROWS * 8 / T256; i++) {
-        const int p = i * T256 + tid;
+    for (int i = 0; i < ROWS * 4 / T; i++) {
+        const int p = i * T + tid;
         const uint16_t *g;
         if (!KMAJOR) {
-            const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+            const int row = p >> 2, c = (p & 3) ^ (((row >> 2) & 1) << 1);
             g = src + size_t(row0 + row) * ld + k0 + (c << 3);
         } else {
-            const int half = p >> 10, krow = (p >> 4) & 63, c16 = p & 15;
+            const int half = p >> 9, krow = (p >> 4) & 31, c16 = p & 15;
             const int c32 = (c16 >> 1) ^ ((krow & 3) | (((krow >> 3) & 1) << 2));
             g = src + size_t(k0 + krow) * ld + row0 + half * 128 + (((c32 << 1) | (c16 & 1)) << 3);
         }
@@ -50,20 +71,32 @@ __device__ __forceinline__ void dma_tile(char *img, const uint16_t *__restrict__
     }
 }
 
+// 16 rows x 32 k fragment of a stage image: lane holds row (lane&15), k = 8*(lane>>4)+j.
 template <bool KMAJOR>
-__device__ __forceinline__ bf16x8 frag256(const char *img, int row0, int kk, int lane) {
-    if (!KMAJOR) return kc_frag(img, row0, kk, lane);
-    else return st_frag(img + (row0 >> 7) * (64 * 128 * 2), row0 & 127, kk, lane);
+__device__ __forceinline__ bf16x8 frag32(const char *img, int row0, int lane) {
+    if (!KMAJOR) return *reinterpret_cast<const bf16x8 *>(img + kc32_off(row0 + (lane & 15), lane >> 4));
+    else return st_frag(img + (row0 >> 7) * (32 * 128 * 2), row0 & 127, 0, lane);
 }
 
-template <bool A_KM, bool B_KM, int BN_>
-__global__ __launch_bounds__(T256, 2) void gemm256_kernel(const sfcvit_gemm_args g, int k_per_split) {
-    constexpr int NF = BN_ / 64;                  // n-fragments per wave
-    constexpr int B_BYTES = BN_ * 64 * 2;
-    constexpr int BUF = A_BYTES + B_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: [2][A | B]
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Wait until at most `stages` (0..3) stages of G LDS-DMA instructions each are outstanding.
+template <int G>
+__device__ __forceinline__ void wait_stages(int stages) {
+    if (stages >= 3) wait_vm<3 * G>();
+    else if (stages == 2) wait_vm<2 * G>();
+    else if (stages == 1) wait_vm<G>();
+    else wait_vm<0>();
+}
+
+template <bool A_KM, bool B_KM, int BN_, bool HEAVY>
+__global__ __launch_bounds__(Cfg<BN_>::T, 2) void gemm256_kernel(const sfcvit_gemm_args g, int k_per_split) {
+    using C = Cfg<BN_>;
+    constexpr int NF = 4;                         // n-fragments per wave (wave tile 128 x 64)
+    constexpr int STAGE = C::STAGE, G = C::G, NSLOT = C::NSLOT, T = C::T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: ring of NSLOT x [A | B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / C::WN, wn = wave % C::WN;
     const int tiles_n = g.N / BN_;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * BN_;
@@ -71,7 +104,7 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const sfcvit_gemm_args
     const uint16_t *B = static_cast<const uint16_t *>(g.b);
     const int kbeg = blockIdx.z * k_per_split;
     const int kend = min(g.K, kbeg + k_per_split);
-    const int nk = (kend - kbeg) / 64;
+    const int nk = (kend - kbeg) / 32;            // stages
 
     f32x4 acc[8][NF];
 #pragma unroll
@@ -79,41 +112,69 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const sfcvit_gemm_args
 #pragma unroll
         for (int j = 0; j < NF; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    dma_tile<A_KM, 256>(smem, A, g.lda, m0, kbeg, tid);
-    dma_tile<B_KM, BN_>(smem + A_BYTES, B, g.ldb, n0, kbeg, tid);
-    __syncthreads();   // LDS-DMA pending => hipcc drains vmcnt(0) here
+    auto issue = [&](int s) {
+        char *slot = smem + (s % NSLOT) * STAGE;
+        dma_stage<A_KM, 256, T>(slot, A, g.lda, m0, kbeg + s * 32, tid);
+        dma_stage<B_KM, BN_, T>(slot + A_STAGE, B, g.ldb, n0, kbeg + s * 32, tid);
+    };
+    // Fragment registers: B double-buffered across stages, A in two halves (rows 0-63 / 64-127 of
+    // the wave tile) that are re-loaded just in time -- 64 VGPRs instead of 96 for two full sets.
+    bf16x8 fb0[NF], fb1[NF], fa_lo[4], fa_hi[4];
+    auto read_b = [&](int s, bf16x8 (&fb)[NF]) {
+        const char *slot = smem + (s % NSLOT) * STAGE + A_STAGE;
+#pragma unroll
+        for (int j = 0; j < NF; j++) fb[j] = frag32<B_KM>(slot, wn * 64 + j * 16, lane);
+    };
+    auto read_a = [&](int s, bf16x8 (&fa)[4], int half) {
+        const char *slot = smem + (s % NSLOT) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; i++) fa[i] = frag32<A_KM>(slot, wm * 128 + (4 * half + i) * 16, lane);
+    };
+    auto mma_half = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[NF], int half) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < NF; j++)
+                acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[4 * half + i][j], 0, 0, 0);
+    };
+    // One stage (fa_lo and cb hold stage s):
+    //   read A rows 64-127 of stage s | 16 MFMAs (rows 0-63) | all waves: stage s+1 landed and
+    //   stage s fully read -> barrier | refill the slot of stage s with stage s+NSLOT | read B and
+    //   A rows 0-63 of stage s+1 | 16 MFMAs (rows 64-127).  Every LDS read is issued one MFMA
+    //   half (>= 256 cycles) before its first use.
+    auto stage = [&](int s, const bf16x8 (&cb)[NF], bf16x8 (&nb)[NF]) {
+        read_a(s, fa_hi, 1);
+        mma_half(fa_lo, cb, 0);
+        if (s + 1 < nk) {
+            wait_stages<G>(min(s + NSLOT - 1, nk - 1) - (s + 1));   // stages issued beyond s+1 may stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of stage s are complete
+            __builtin_amdgcn_s_barrier();
+            if (s + NSLOT < nk) issue(s + NSLOT);
+            read_b(s + 1, nb);
+            read_a(s + 1, fa_lo, 0);
+        }
+        mma_half(fa_hi, cb, 1);
+    };
 
-    for (int kt = 0; kt < nk; kt++) {
-        const char *ia = smem + (kt & 1) * BUF;
-        const char *ib = ia + A_BYTES;
-        if (kt + 1 < nk && g.force_generic != 3) {
-            char *oa = smem + ((kt + 1) & 1) * BUF;
-            dma_tile<A_KM, 256>(oa, A, g.lda, m0, kbeg + (kt + 1) * 64, tid);
-            dma_tile<B_KM, BN_>(oa + A_BYTES, B, g.ldb, n0, kbeg + (kt + 1) * 64, tid);
-        }
-        if (g.force_generic != 2)
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            bf16x8 fb[NF];
-#pragma unroll
-            for (int j = 0; j < NF; j++) fb[j] = frag256<B_KM>(ib, wn * (BN_ / 4) + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const bf16x8 fa = frag256<A_KM>(ia, wm * 128 + i * 16, kk, lane);
-#pragma unroll
-                for (int j = 0; j < NF; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
-            }
-        }
-        __syncthreads();
+    for (int s = 0; s < NSLOT; s++)
+        if (s < nk) issue(s);
+    wait_stages<G>(min(NSLOT - 1, nk - 1));
+    __builtin_amdgcn_s_barrier();
+    read_b(0, fb0);
+    read_a(0, fa_lo, 0);
+    for (int s = 0; s < nk; s += 2) {
+        stage(s, fb0, fb1);
+        if (s + 1 < nk) stage(s + 1, fb1, fb0);
     }
+    __syncthreads();   // every wave is done with the operand ring: the epilogue reuses it
 
-    // acc[i][j][r] = C[m][n], m = m0 + wm*128 + i*16 + (lane&15), n = n0 + wn*BN/4 + j*16 + 4*(lane>>4) + r
+    // acc[i][j][r] = C[m][n], m = m0 + wm*128 + i*16 + (lane&15), n = n0 + wn*64 + j*16 + 4*(lane>>4) + r
     if (gridDim.z > 1) {
         float *slab = static_cast<float *>(g.workspace) + size_t(blockIdx.z) * g.M * g.N;
 #pragma unroll
         for (int j = 0; j < NF; j++) {
-            const int n = n0 + wn * (BN_ / 4) + j * 16 + 4 * (lane >> 4);
+            const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int m = m0 + wm * 128 + i * 16 + (lane & 15);
@@ -122,30 +183,29 @@ __global__ __launch_bounds__(T256, 2) void gemm256_kernel(const sfcvit_gemm_args
         }
         return;
     }
-    const uint16_t *bias = static_cast<const uint16_t *>(g.bias);
-#pragma unroll
-    for (int j = 0; j < NF; j++) {
-        const int n = n0 + wn * (BN_ / 4) + j * 16 + 4 * (lane >> 4);
-        float bv[4];
-        load_bias4(bias, n, bv);
-#pragma unroll
-        for (int i = 0; i < 8; i++) epilogue4(g, m0 + wm * 128 + i * 16 + (lane & 15), n, acc[i][j], bv);
-    }
+    epilogue_tile<8, NF, HEAVY>(g, acc, reinterpret_cast<float *>(smem) + wave * (32 * (16 * NF + 4)), m0 + wm * 128,
+                                n0 + wn * 64, lane);
 }
 
-template <bool A_KM, bool B_KM, int BN_>
-int launch(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s) {
-    constexpr size_t lds = 2 * (A_BYTES + BN_ * 64 * 2);
+template <bool A_KM, bool B_KM, int BN_, bool HEAVY>
+int launch1(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s) {
+    constexpr size_t lds = Cfg<BN_>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_kernel<A_KM, B_KM, BN_>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_kernel<A_KM, B_KM, BN_, HEAVY>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
             return check_launch("gemm256 attribute");
         attr_set = true;
     }
-    dim3 grid((a.M / 256) * (a.N / BN_), 1, splits), block(T256);
-    hipLaunchKernelGGL((gemm256_kernel<A_KM, B_KM, BN_>), grid, block, lds, s, a, k_per_split);
+    dim3 grid((a.M / 256) * (a.N / BN_), 1, splits), block(Cfg<BN_>::T);
+    hipLaunchKernelGGL((gemm256_kernel<A_KM, B_KM, BN_, HEAVY>), grid, block, lds, s, a, k_per_split);
     return check_launch("gemm256");
+}
+
+template <bool A_KM, bool B_KM, int BN_>
+int launch(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s) {
+    if (a.act == SFCVIT_ACT_GELU || a.dact == SFCVIT_ACT_GELU) return launch1<A_KM, B_KM, BN_, true>(a, splits, k_per_split, s);
+    return launch1<A_KM, B_KM, BN_, false>(a, splits, k_per_split, s);
 }
 
 }  // namespace
@@ -153,11 +213,7 @@ int launch(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s
 // Called by sfcvit_gemm after argument validation.  Returns -1 when the shape is not
 // eligible (caller falls back to the generic kernel), else a status code.
 int gemm256_dispatch(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s) {
-    if (a.M % 256 || a.N % 128 || a.K % 64 || k_per_split % 64) return -1;
-    // Measured on ViT-B shapes (tools/bench_gemm.py): with one k-tile of prefetch this kernel wins
-    // on the weight-gradient layout (both operands k-major, long K) and loses to the generic
-    // kernel's two independent workgroups per CU elsewhere; force_generic == 4 forces it (tests).
-    if (!(a.a_kmajor && a.b_kmajor) && a.force_generic != 4 && a.force_generic != 2 && a.force_generic != 3) return -1;
+    if (a.M % 256 || a.N % 128 || a.K % 32 || k_per_split % 32) return -1;
     // BN = 256 unless that leaves the last round of workgroups mostly idle on 256 CUs.
     bool bn256 = a.N % 256 == 0;
     if (bn256) {
@@ -165,6 +221,16 @@ int gemm256_dispatch(const sfcvit_gemm_args &a, int splits, int k_per_split, hip
         const long rounds = (t + 255) / 256;
         if (t < 200 || double(t) / double(rounds * 256) < 0.85) bn256 = false;
     }
+    // Measured on the ViT-B shapes (tools/bench_gemm.py, profiles/r1): the 256 x 128 two-workgroup
+    // configuration wins when both operands are k-contiguous (forward GEMMs: 730-880 TFLOP/s vs
+    // 650-760 generic, 650-820 for 256 x 256); with a k-major operand (dX, dW: transposed LDS reads,
+    // twice the LDS instructions) the generic kernel's 128 x 128 tiles are as fast or faster.
+    if (a.force_generic == 0) {
+        if (a.a_kmajor || a.b_kmajor) return -1;
+        bn256 = false;
+    }
+    if (a.force_generic == 6) bn256 = false;             // tests / benchmarking: force the 256 x 128 configuration
+    if (a.force_generic == 7 && a.N % 256 == 0) bn256 = true;
 #define SFCVIT_GO(AK, BK)                                                                          \
     return bn256 ? launch<AK, BK, 256>(a, splits, k_per_split, s) : launch<AK, BK, 128>(a, splits, k_per_split, s)
     if (!a.a_kmajor && !a.b_kmajor) SFCVIT_GO(false, false);

@@ -110,60 +110,141 @@ __device__ __forceinline__ void store_partial(const f32x4 (&acc)[4][4], float *s
     }
 }
 
-// Bias of 4 consecutive columns as fp32.
-__device__ __forceinline__ void load_bias4(const uint16_t *bias, int n, float (&bv)[4]) {
-    bv[0] = bv[1] = bv[2] = bv[3] = 0.f;
-    if (bias) {
-        const u32x2 b2 = *reinterpret_cast<const u32x2 *>(bias + n);
-        bv[0] = bf2f(uint16_t(b2[0])); bv[1] = bf2f(uint16_t(b2[0] >> 16));
-        bv[2] = bf2f(uint16_t(b2[1])); bv[3] = bf2f(uint16_t(b2[1] >> 16));
+__device__ __forceinline__ void unpack8f(const u32x4 &v, float *f) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f[2 * i] = bf2f(uint16_t(v[i]));
+        f[2 * i + 1] = bf2f(uint16_t(v[i] >> 16));
     }
 }
 
-// Fused epilogue of one 4-vector C[m][n..n+3] (order documented at sfcvit_gemm in include/sfcvit.h).
-__device__ __forceinline__ void epilogue4(const sfcvit_gemm_args &g, int m, int n, const f32x4 &acc, const float (&bv)[4]) {
-    float v[4];
+// Fused epilogue of NV (4 or 8) consecutive columns C[m][n .. n+NV-1], in the order documented at
+// sfcvit_gemm (include/sfcvit.h): bias, aux_out, act, dropout, residual, dact, store.
+// HEAVY = the launch uses the erf GELU (forward or gradient); everything else compiles without it.
+template <int NV, bool HEAVY>
+__device__ __forceinline__ void epilogue_vec(const sfcvit_gemm_args &g, int m, int n, float (&v)[8], const float (&bv)[8]) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = acc[r] + bv[r];
+    for (int r = 0; r < NV; r++) v[r] += bv[r];
     if (g.aux_out) {
-        u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(g.aux_out) + size_t(m) * g.ldaux + n) = o;
+        uint16_t *p = static_cast<uint16_t *>(g.aux_out) + size_t(m) * g.ldaux + n;
+        if (NV == 8) *reinterpret_cast<u32x4 *>(p) = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        else *reinterpret_cast<u32x2 *>(p) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
     }
     if (g.act == SFCVIT_ACT_RELU) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-    } else if (g.act == SFCVIT_ACT_GELU) {
+        for (int r = 0; r < NV; r++) v[r] = fmaxf(v[r], 0.f);
+    } else if (HEAVY && g.act == SFCVIT_ACT_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = gelu_erf(v[r]);
+        for (int r = 0; r < NV; r++) v[r] = gelu_erf(v[r]);
     }
     if (g.dropout_p > 0.f) {
         const uint32_t th = drop_thresh(g.dropout_p);
         const float sc = 1.f / (1.f - g.dropout_p);
         const uint64_t pair = uint64_t(m) * uint64_t((g.N + 1) >> 1) + uint64_t(n >> 1);
-        bool k[4];
-        drop_keep2(g.dropout_seed, pair, th, k[0], k[1]);
-        drop_keep2(g.dropout_seed, pair + 1, th, k[2], k[3]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = k[r] ? v[r] * sc : 0.f;
+        for (int q = 0; q < NV / 2; q++) {
+            bool k0, k1;
+            drop_keep2(g.dropout_seed, pair + q, th, k0, k1);
+            v[2 * q] = k0 ? v[2 * q] * sc : 0.f;
+            v[2 * q + 1] = k1 ? v[2 * q + 1] * sc : 0.f;
+        }
     }
     if (g.residual) {
-        const u32x2 r2 = *reinterpret_cast<const u32x2 *>(static_cast<const uint16_t *>(g.residual) + size_t(m) * g.ldr + n);
-        v[0] += bf2f(uint16_t(r2[0])); v[1] += bf2f(uint16_t(r2[0] >> 16));
-        v[2] += bf2f(uint16_t(r2[1])); v[3] += bf2f(uint16_t(r2[1] >> 16));
+        const uint16_t *p = static_cast<const uint16_t *>(g.residual) + size_t(m) * g.ldr + n;
+        float rv[8];
+        if (NV == 8) {
+            unpack8f(*reinterpret_cast<const u32x4 *>(p), rv);
+        } else {
+            const u32x2 r2 = *reinterpret_cast<const u32x2 *>(p);
+            rv[0] = bf2f(uint16_t(r2[0])); rv[1] = bf2f(uint16_t(r2[0] >> 16));
+            rv[2] = bf2f(uint16_t(r2[1])); rv[3] = bf2f(uint16_t(r2[1] >> 16));
+        }
+#pragma unroll
+        for (int r = 0; r < NV; r++) v[r] += rv[r];
     }
     if (g.dact != SFCVIT_ACT_NONE) {
-        const u32x2 a2 = *reinterpret_cast<const u32x2 *>(static_cast<const uint16_t *>(g.aux_in) + size_t(m) * g.ldaux + n);
-        const float a[4] = {bf2f(uint16_t(a2[0])), bf2f(uint16_t(a2[0] >> 16)), bf2f(uint16_t(a2[1])), bf2f(uint16_t(a2[1] >> 16))};
+        const uint16_t *p = static_cast<const uint16_t *>(g.aux_in) + size_t(m) * g.ldaux + n;
+        float a[8];
+        if (NV == 8) {
+            unpack8f(*reinterpret_cast<const u32x4 *>(p), a);
+        } else {
+            const u32x2 a2 = *reinterpret_cast<const u32x2 *>(p);
+            a[0] = bf2f(uint16_t(a2[0])); a[1] = bf2f(uint16_t(a2[0] >> 16));
+            a[2] = bf2f(uint16_t(a2[1])); a[3] = bf2f(uint16_t(a2[1] >> 16));
+        }
         const float ds = g.dact_scale != 0.f ? g.dact_scale : 1.f;
+        if (!HEAVY || g.dact == SFCVIT_ACT_RELU) {
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            v[r] = (g.dact == SFCVIT_ACT_RELU) ? (a[r] > 0.f ? v[r] * ds : 0.f) : v[r] * gelu_erf_grad(a[r]) * ds;
+            for (int r = 0; r < NV; r++) v[r] = a[r] > 0.f ? v[r] * ds : 0.f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < NV; r++) v[r] = v[r] * gelu_erf_grad(a[r]) * ds;
+        }
     }
     if (g.c_is_f32) {
-        *reinterpret_cast<f32x4 *>(static_cast<float *>(g.c) + size_t(m) * g.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+        float *c = static_cast<float *>(g.c) + size_t(m) * g.ldc + n;
+        *reinterpret_cast<f32x4 *>(c) = f32x4{v[0], v[1], v[2], v[3]};
+        if (NV == 8) *reinterpret_cast<f32x4 *>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
     } else {
-        u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n) = o;
+        uint16_t *c = static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n;
+        if (NV == 8) *reinterpret_cast<u32x4 *>(c) = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        else *reinterpret_cast<u32x2 *>(c) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    }
+}
+
+// Epilogue of one wave's (16*NI) x (16*NF) accumulator tile through LDS.
+//
+// The MFMA leaves a lane with 4 consecutive n of one m, so a direct store moves 8 bytes per lane
+// into 16 different rows per instruction.  Here the wave transposes 32 rows at a time through a
+// private fp32 LDS patch ([32][16*NF + 4], padded against bank conflicts) and then owns 8
+// consecutive n per lane: bias / residual / aux reads and the C store are 16-byte vectors, 8
+// lanes per 128-byte row segment.
+// `patch` = this wave's LDS region of 32 * (16*NF + 4) * 4 bytes; the operand tiles must be dead
+// (call after the k-loop's final barrier).  M, N bounds are honoured (N % 4 == 0).
+// Code size matters here: the fused epilogue has a wide tree of wave-uniform options, and fully
+// unrolling it per vector made the kernels ~230 KB of code that thrashed the instruction cache
+// (the epilogue alone took 140 us on the QKV shape).  So the read/compute/store loop of a pass is
+// a real loop (unroll 1), and the erf-GELU variants are compiled only into HEAVY instantiations.
+template <int NI, int NF, bool HEAVY>
+__device__ __forceinline__ void epilogue_tile(const sfcvit_gemm_args &g, const f32x4 (&acc)[NI][NF], float *patch,
+                                              int m_base, int n_base, int lane) {
+    constexpr int WC = 16 * NF, LD = WC + 4, VPR = WC / 8, VPL = 32 * VPR / 64;
+    const int cg = lane % VPR;
+    const int n = n_base + 8 * cg;
+    const int nvalid = g.N - n;                      // >= 8: full vector, 4: half, <= 0: nothing
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g.bias && nvalid >= 4) {
+        const uint16_t *bp = static_cast<const uint16_t *>(g.bias) + n;
+        const u32x2 b0 = *reinterpret_cast<const u32x2 *>(bp);
+        bv[0] = bf2f(uint16_t(b0[0])); bv[1] = bf2f(uint16_t(b0[0] >> 16));
+        bv[2] = bf2f(uint16_t(b0[1])); bv[3] = bf2f(uint16_t(b0[1] >> 16));
+        if (nvalid >= 8) {
+            const u32x2 b1 = *reinterpret_cast<const u32x2 *>(bp + 4);
+            bv[4] = bf2f(uint16_t(b1[0])); bv[5] = bf2f(uint16_t(b1[0] >> 16));
+            bv[6] = bf2f(uint16_t(b1[1])); bv[7] = bf2f(uint16_t(b1[1] >> 16));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NI / 2; p++) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int j = 0; j < NF; j++)
+                *reinterpret_cast<f32x4 *>(patch + (16 * ii + (lane & 15)) * LD + 16 * j + 4 * (lane >> 4)) = acc[2 * p + ii][j];
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < VPL; k++) {
+            const int row = (k * 64 + lane) / VPR;
+            const int m = m_base + 32 * p + row;
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(patch + row * LD + 8 * cg);
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(patch + row * LD + 8 * cg + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (m < g.M) {
+                if (nvalid >= 8) epilogue_vec<8, HEAVY>(g, m, n, v, bv);
+                else if (nvalid >= 4) epilogue_vec<4, HEAVY>(g, m, n, v, bv);
+            }
+        }
+        __syncthreads();
     }
 }
 

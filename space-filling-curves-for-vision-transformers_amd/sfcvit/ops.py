@@ -83,13 +83,9 @@ def _rows2d(t, dtype, name):
 # GEMM
 # ----------------------------------------------------------------------------
 def auto_splitk(M, N, K):
-    """Split K when the output has too few tiles to fill 256 CUs (weight-gradient shapes)."""
-    if M % 256 == 0 and N % 128 == 0 and K % 64 == 0:        # 256-wide LDS-DMA kernel, 1 WG / CU
-        tiles = (M // 256) * (N // 256 if N % 256 == 0 else N // 128)
-        if tiles >= 200 or K < 2048:
-            return 1
-        return max(1, min(512 // tiles, K // 1024))
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)          # generic 128 x 128 kernel, 2 WG / CU
+    """Split K when the output has too few 128 x 128 tiles to fill 256 CUs at 2 workgroups each
+    (weight-gradient shapes: 36-144 tiles, K = batch * tokens)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 256 or K < 2048:
         return 1
     return max(1, min((768 + tiles - 1) // tiles, K // 512))
@@ -103,7 +99,7 @@ def next_seed():
 
 def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, residual=None,
          aux_in=None, dact=ACT_NONE, want_aux=False, out_f32=False, splitk=None, force_generic=False,
-         dropout_p=0.0, dropout_seed=0, dact_scale=1.0):
+         dropout_p=0.0, dropout_seed=0, dact_scale=1.0, out=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  a: [M,K] (or [K,M] if a_kmajor),
     b: [N,K] (or [K,N] if b_kmajor), bf16.  Returns C (and the pre-activation if want_aux)."""
     _rows2d(a, _BF16, "gemm a")
@@ -112,13 +108,18 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
     N, Kb = (b.shape[1], b.shape[0]) if b_kmajor else (b.shape[0], b.shape[1])
     if K != Kb:
         raise ValueError(f"gemm: contraction mismatch {K} vs {Kb}")
-    c = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else _BF16)
+    if out is not None:
+        c = _rows2d(out, torch.float32 if out_f32 else _BF16, "gemm out")
+        if c.shape != (M, N):
+            raise ValueError(f"gemm out: expected {(M, N)}, got {tuple(c.shape)}")
+    else:
+        c = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else _BF16)
     aux = torch.empty((M, N), device=a.device, dtype=_BF16) if want_aux else None
     args = _lib.GemmArgs()
     args.a, args.b, args.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
     args.bias = _need(bias, _BF16, "gemm bias", 1).data_ptr() if bias is not None else None
     args.M, args.N, args.K = M, N, K
-    args.lda, args.ldb, args.ldc = a.stride(0), b.stride(0), N
+    args.lda, args.ldb, args.ldc = a.stride(0), b.stride(0), c.stride(0)
     if residual is not None:
         _rows2d(residual, _BF16, "gemm residual")
         args.residual, args.ldr = residual.data_ptr(), residual.stride(0)
@@ -143,7 +144,8 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
         args.workspace, args.workspace_bytes = ws.data_ptr(), nbytes
     args.splitk = splitk
     args.force_generic = int(force_generic)
-    key = "gemm_kernel<%s,%s>" % ("true" if a_kmajor else "false", "true" if b_kmajor else "false")
+    key = "gemm %s" % {(False, False): "y=x.W^T (k-contig, k-contig)", (False, True): "dx=dy.W (k-contig, k-major)",
+                       (True, True): "dW=dy^T.x (k-major, k-major)", (True, False): "(k-major, k-contig)"}[(a_kmajor, b_kmajor)]
     check(_launch(key, 2.0 * M * N * K, lambda: lib.sfcvit_gemm(ctypes.byref(args), _stream())), "sfcvit_gemm")
     return (c, aux) if want_aux else c
 

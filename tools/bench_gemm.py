@@ -33,25 +33,32 @@ def main():
         a = torch.randn((k, m) if akm else (m, k), device="cuda", generator=g).bfloat16()
         b = torch.randn((k, n) if bkm else (n, k), device="cuda", generator=g).bfloat16()
         cases.append((name, m, n, k, akm, bkm, a, b))
+    modes = {"auto": 0, "generic": 1, "256x256": 7, "256x128": 6}
     for c in cases:
-        ops.gemm(c[6], c[7], a_kmajor=c[4], b_kmajor=c[5])
+        for md in modes.values():
+            ops.gemm(c[6], c[7], a_kmajor=c[4], b_kmajor=c[5], force_generic=md)
     torch.cuda.synchronize()
-    times = {c[0]: [] for c in cases}
+    times = {(c[0], k): [] for c in cases for k in modes}
     for _ in range(rounds):
         for name, m, n, k, akm, bkm, a, b in cases:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                ops.gemm(a, b, a_kmajor=akm, b_kmajor=bkm)
-            e1.record()
-            torch.cuda.synchronize()
-            times[name].append(e0.elapsed_time(e1) / 3)
-    tot = 0.0
+            for mk, md in modes.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    ops.gemm(a, b, a_kmajor=akm, b_kmajor=bkm, force_generic=md)
+                e1.record()
+                torch.cuda.synchronize()
+                times[(name, mk)].append(e0.elapsed_time(e1) / 3)
+    tot = {k: 0.0 for k in modes}
     for name, m, n, k, *_ in cases:
-        t = sorted(times[name])[len(times[name]) // 2]
-        tot += t
-        print(f"{name:40s} {t * 1e3:8.1f} us  {2.0 * m * n * k / t / 1e9:7.1f} TFLOP/s  (min {min(times[name]) * 1e3:.1f})")
-    print(f"sum {tot:.3f} ms")
+        row = f"{name:38s}"
+        for mk in modes:
+            ts = times[(name, mk)]
+            t = sorted(ts)[len(ts) // 2]
+            tot[mk] += t
+            row += f" | {mk} {t * 1e3:6.1f} us {2.0 * m * n * k / t / 1e9:6.0f} TF"
+        print(row)
+    print("sum ms: " + ", ".join(f"{k} {v:.3f}" for k, v in tot.items()))
 
 
 if __name__ == "__main__":

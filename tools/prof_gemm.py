@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Few launches of chosen GEMM shapes for rocprofv3 --pmc runs (see profiles/)."""
+"""Few launches of chosen GEMM shapes/kernels for rocprofv3 --pmc runs (see profiles/).
+usage: prof_gemm.py shape[,shape...] mode    (mode = force_generic value: 0 auto, 1 generic, 7 256x256, 6 256x128)"""
 import os
 import sys
 
@@ -16,12 +17,12 @@ SHAPES = {
     "dw_ffn1": (3072, 768, M, True, True),
 }
 which = sys.argv[1].split(",") if len(sys.argv) > 1 else list(SHAPES)
-generic = len(sys.argv) > 2 and sys.argv[2] == "generic"
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 g = torch.Generator(device="cuda").manual_seed(0)
 for name in which:
     m, n, k, akm, bkm = SHAPES[name]
     a = torch.randn((k, m) if akm else (m, k), device="cuda", generator=g).bfloat16()
     b = torch.randn((k, n) if bkm else (n, k), device="cuda", generator=g).bfloat16()
     for _ in range(3):
-        ops.gemm(a, b, a_kmajor=akm, b_kmajor=bkm, force_generic=generic)
+        ops.gemm(a, b, a_kmajor=akm, b_kmajor=bkm, force_generic=mode)
     torch.cuda.synchronize()
