@@ -17,97 +17,13 @@
 //       dV^T += dO^T P, dK^T += Q^T dS   A: tr-reads of dO / Q   B: P / dS accumulators
 //   backward, dQ kernel    (wave = 16 queries, loop over 64-key blocks in LDS)
 //       S^T = K Q^T, dP^T = V dO^T ; dQ^T += K^T dS^T  (A: tr-read of K, B: dS^T)
+#include "attention_common.h"
 #include "common_host.h"
-#include "device_common.h"
 
 namespace sfcvit {
 namespace {
 
-constexpr int HD = 64;
-constexpr int THREADS = 256;
-constexpr int BLK = 64;                 // rows (keys or queries) per LDS block
-constexpr int IMG_BYTES = BLK * HD * 2;  // 8 KiB
-
-// [64 rows][64 cols] bf16 image for transposed reads only: 32-B chunk ^ ((row >> 1) & 3).
-__device__ __forceinline__ int vt_off(int row, int col) {
-    return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + ((col & 15) << 1);
-}
-
-// Stage 64 rows x 64 cols from global (row stride `ld` elements) into an LDS image.
-// Rows >= nvalid are zero-filled.  VT = false: "kc" layout, true: "vt" layout.
-template <bool VT>
-__device__ __forceinline__ void stage64(char *img, const uint16_t *__restrict__ src, int ld, int row0, int nvalid,
-                                        int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int v = tid + THREADS * i;
-        const int r = v >> 3, c16 = v & 7;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (row0 + r < nvalid) val = *reinterpret_cast<const u32x4 *>(src + size_t(row0 + r) * ld + c16 * 8);
-        const int off = VT ? vt_off(r, c16 * 8) : kc_off(r, c16);
-        *reinterpret_cast<u32x4 *>(img + off) = val;
-    }
-}
-
-// A-operand fragment of X^T for a 32-deep contraction over image rows:
-// lane (g, i) gets X[rows r_lo+4g+{0..3}, r_hi+4g+{0..3}][col0 + i].
-template <bool VT>
-__device__ __forceinline__ bf16x8 tr_frag(const char *img, int r_lo, int r_hi, int col0, int lane) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const int col = col0 + 4 * p;
-    const int ra = r_lo + 4 * g + q, rb = r_hi + 4 * g + q;
-    int oa, ob;
-    if (VT) {
-        oa = vt_off(ra, col);
-        ob = vt_off(rb, col);
-    } else {
-        oa = kc_off(ra, col >> 3) + ((col & 7) << 1);
-        ob = kc_off(rb, col >> 3) + ((col & 7) << 1);
-    }
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFCVIT_LDS bf16x4 *)(img + oa));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFCVIT_LDS bf16x4 *)(img + ob));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-
-// Row fragment straight from global: lane (g, i) gets X[row0 + i][32*kk + 8g .. +7].
-__device__ __forceinline__ bf16x8 global_frag(const uint16_t *__restrict__ src, int ld, int row0, int nvalid, int kk,
-                                              int lane) {
-    const int r = row0 + (lane & 15);
-    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < nvalid) z = *reinterpret_cast<const bf16x8 *>(src + size_t(r) * ld + kk * 32 + 8 * (lane >> 4));
-    return z;
-}
-
-__device__ __forceinline__ bf16x8 pack_frag(const f32x4 &a, const f32x4 &b) {
-    bf16x8 r;
-    r[0] = short(f2bf(a[0])); r[1] = short(f2bf(a[1])); r[2] = short(f2bf(a[2])); r[3] = short(f2bf(a[3]));
-    r[4] = short(f2bf(b[0])); r[5] = short(f2bf(b[1])); r[6] = short(f2bf(b[2])); r[7] = short(f2bf(b[3]));
-    return r;
-}
-
-// reduce over the four 16-lane groups (same lane&15)
-__device__ __forceinline__ float group_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
-}
-
-// Store a transposed accumulator: acc[hf][r] = X[row = lane&15][col = 16hf + 4g + r].
-__device__ __forceinline__ void store_rows(uint16_t *__restrict__ dst, int ld, int row, bool valid, const f32x4 (&acc)[4],
-                                           float mul, int lane) {
-    if (!valid) return;
-#pragma unroll
-    for (int hf = 0; hf < 4; hf++) {
-        u32x2 o = {pack2bf(acc[hf][0] * mul, acc[hf][1] * mul), pack2bf(acc[hf][2] * mul, acc[hf][3] * mul)};
-        *reinterpret_cast<u32x2 *>(dst + size_t(row) * ld + 16 * hf + 4 * (lane >> 4)) = o;
-    }
-}
+using namespace attn;
 
 // ---------------------------------------------------------------------------
 // forward
@@ -124,9 +40,8 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(const sfcvit_attn_arg
     const bool drop = a.dropout_p > 0.f;
     const uint32_t dth = drop_thresh(a.dropout_p);
     const float dsc = 1.f / (1.f - a.dropout_p);
-    // mask row of this lane's query, in pairs of keys
-    const uint64_t drow = (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q0 + (lane & 15));
-    const uint64_t dpair_row = drow * uint64_t((N + 1) >> 1);
+    // mask row of this lane's query
+    const uint32_t drk = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q0 + (lane & 15)));
 
     bf16x8 qf[2];
     qf[0] = global_frag(qp, ld, q0, N, 0, lane);
@@ -177,12 +92,10 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(const sfcvit_attn_arg
         if (drop) {
 #pragma unroll
             for (int kf = 0; kf < 4; kf++) {
-                const uint64_t pr = dpair_row + uint64_t((k0 + 16 * kf + 4 * (lane >> 4)) >> 1);
-                bool k[4];
-                drop_keep2(a.dropout_seed, pr, dth, k[0], k[1]);
-                drop_keep2(a.dropout_seed, pr + 1, dth, k[2], k[3]);
+                float keep[4];
+                drop_keep4(drk, k0 + 16 * kf + 4 * (lane >> 4), dth, dsc, keep);
 #pragma unroll
-                for (int r = 0; r < 4; r++) s[kf][r] = k[r] ? s[kf][r] * dsc : 0.f;
+                for (int r = 0; r < 4; r++) s[kf][r] *= keep[r];
             }
         }
 #pragma unroll
@@ -196,6 +109,7 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(const sfcvit_attn_arg
                                                                 o[hf], 0, 0, 0);
         }
     }
+    mfma_fence();
     const float l_tot = group_sum(l_run);
     const int q = q0 + (lane & 15);
     uint16_t *out = static_cast<uint16_t *>(a.out) + size_t(b) * N * D + h * HD;
@@ -292,7 +206,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(const sfcvit_attn_
                     float keep = 1.f;
                     if (drop) {
                         bool k0b, k1b;
-                        drop_keep2(a.dropout_seed, (dbh + uint64_t(q0 + ql)) * uint64_t((N + 1) >> 1) + uint64_t(dkey >> 1), dth, k0b, k1b);
+                        drop_keep2(drop_row_key(a.dropout_seed, dbh + uint64_t(q0 + ql)), uint32_t(dkey >> 1), dth, k0b, k1b);
                         keep = ((dkey & 1) ? k1b : k0b) ? dsc : 0.f;
                     }
                     p[t][r] = pv * keep;                                   // dropped probabilities feed dV
@@ -311,6 +225,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(const sfcvit_attn_
     }
     const int key = key0 + (lane & 15);
     uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
+    mfma_fence();
     store_rows(dbase + D, ld, key, key < N, dk, 1.f, lane);
     store_rows(dbase + 2 * D, ld, key, key < N, dv, 1.f, lane);
 }
@@ -334,7 +249,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(const sfcvit_attn_a
     const bool drop = a.dropout_p > 0.f;
     const uint32_t dth = drop_thresh(a.dropout_p);
     const float dsc = 1.f / (1.f - a.dropout_p);
-    const uint64_t dpair_row = ((uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q)) * uint64_t((N + 1) >> 1);
+    const uint32_t drk = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
 
     bf16x8 qf[2], dof[2];
 #pragma unroll
@@ -365,14 +280,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(const sfcvit_attn_a
                 }
                 // s[r] = S^T[key = k0 + 16kfi + 4g + r][q]; keys >= N have K = V = 0 and add nothing
                 float keep[4] = {1.f, 1.f, 1.f, 1.f};
-                if (drop) {
-                    const uint64_t pr = dpair_row + uint64_t((k0 + 16 * kfi + 4 * (lane >> 4)) >> 1);
-                    bool k[4];
-                    drop_keep2(a.dropout_seed, pr, dth, k[0], k[1]);
-                    drop_keep2(a.dropout_seed, pr + 1, dth, k[2], k[3]);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) keep[r] = k[r] ? dsc : 0.f;
-                }
+                if (drop) drop_keep4(drk, k0 + 16 * kfi + 4 * (lane >> 4), dth, dsc, keep);
 #pragma unroll
                 for (int r = 0; r < 4; r++) ds[t][r] = __expf(s[r] * scale - lse_q) * (dp[r] * keep[r] - del_q) * scale;
             }
@@ -384,6 +292,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(const sfcvit_attn_a
         }
     }
     uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
+    mfma_fence();
     store_rows(dbase, ld, q, q < N, dq, 1.f, lane);
 }
 
@@ -400,12 +309,18 @@ int check_args(const sfcvit_attn_args *a, const char *what, bool bwd) {
 }
 
 }  // namespace
+
+// attention_seq.hip: whole-sequence kernels; return -1 when N is too long for them.
+int attn_seq_fwd(const sfcvit_attn_args &a, hipStream_t s);
+int attn_seq_bwd(const sfcvit_attn_args &a, hipStream_t s);
+
 }  // namespace sfcvit
 
 using namespace sfcvit;
 
 extern "C" int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream) {
     if (int rc = check_args(a, "attention_fwd", false)) return rc;
+    if (int rc = attn_seq_fwd(*a, static_cast<hipStream_t>(stream)); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a);
     return check_launch("attention_fwd");
@@ -418,6 +333,7 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
     hipLaunchKernelGGL(attn_delta_kernel, dim3(unsigned((groups * 8 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s,
                        static_cast<const uint16_t *>(a->dout), static_cast<const uint16_t *>(a->out), a->delta, a->B, a->N, a->H);
     if (int rc = check_launch("attention_bwd delta")) return rc;
+    if (int rc = attn_seq_bwd(*a, s); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
     hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(THREADS), 0, s, *a);
     if (int rc = check_launch("attention_bwd kv")) return rc;

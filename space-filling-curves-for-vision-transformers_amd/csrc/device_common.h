@@ -66,24 +66,38 @@ __device__ __forceinline__ bf16x8 st_frag(const char *img, int col0, int kk, int
 }
 
 // ---- counter-based dropout mask ------------------------------------------------
-// Element (row, col) of a [rows, cols] tensor belongs to pair index row * ceil(cols/2) + col/2;
-// one 32-bit hash per pair gives two 16-bit uniforms; keep iff u16 >= thresh, thresh = p * 65536.
+// Element (row, col) of a [rows, cols] tensor: one 32-bit hash per (row, col/2) pair gives two 16-bit
+// uniforms; keep iff u16 >= thresh, thresh = p * 65536.
 // The same function is evaluated in forward and backward (nothing is stored) and by
 // sfcvit_dropout_mask (tests).  Statistical quality: murmur3 finaliser of (pair, seed).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint64_t pair) {
-    return mix32(uint32_t(pair) * 0x9E3779B1u + mix32(seed + uint32_t(pair >> 32) * 0x7FEB352Du));
+// Two-level form: a per-row key (once per row) and a cheap per-pair finaliser, so kernels that
+// walk along a row (attention: one query row per lane) pay ~5 integer ops per pair.
+__device__ __forceinline__ uint32_t drop_row_key(uint32_t seed, uint64_t row) {
+    return mix32(uint32_t(row) * 0x9E3779B1u + mix32(seed ^ (uint32_t(row >> 32) * 0x7FEB352Du)));
+}
+__device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row_key, uint32_t pair_in_row) {
+    uint32_t x = row_key ^ (pair_in_row * 0x9E3779B1u);
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
+    return x;
 }
 __device__ __forceinline__ uint32_t drop_thresh(float p) { return uint32_t(p * 65536.f + 0.5f); }
-// keep flags of the two elements of a pair
-__device__ __forceinline__ void drop_keep2(uint32_t seed, uint64_t pair, uint32_t thresh, bool &k0, bool &k1) {
-    const uint32_t h = drop_hash(seed, pair);
+// keep flags of the two elements (cols 2*pair, 2*pair+1) of a row
+__device__ __forceinline__ void drop_keep2(uint32_t row_key, uint32_t pair_in_row, uint32_t thresh, bool &k0, bool &k1) {
+    const uint32_t h = drop_pair_hash(row_key, pair_in_row);
     k0 = (h & 0xFFFFu) >= thresh;
     k1 = (h >> 16) >= thresh;
 }
+
+// Wait states between the last MFMA of a sequence and the first VALU / LDS / store read of its
+// accumulators.  hipcc (ROCm 7.2) pads this hazard inside a basic block but was observed to miss it
+// across a taken branch (attention forward: `v_mfma ...; s_cbranch; v_max3 <acc>` read accumulators
+// two instructions after the MFMA and returned pre-MFMA values -- a run-to-run varying row max).
+// 16 states cover the 8-pass bf16 MFMAs; call it wherever control flow separates the two.
+__device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
 
 // 64-lane butterfly reductions.
 __device__ __forceinline__ float wave_sum(float v) {

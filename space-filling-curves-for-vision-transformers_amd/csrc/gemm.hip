@@ -62,6 +62,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const sfcvit_gemm_args
         __syncthreads();
     }
 
+    mfma_fence();
     if (gridDim.z > 1) {
         store_partial(acc, static_cast<float *>(g.workspace) + size_t(blockIdx.z) * g.M * g.N, g.M, g.N, m0, n0, wm, wn, lane);
         return;

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(Cfg<BN_>::T, 2) void gemm256_kernel(const sfcvit_ge
         stage(s, fb0, fb1);
         if (s + 1 < nk) stage(s + 1, fb1, fb0);
     }
+    mfma_fence();
     __syncthreads();   // every wave is done with the operand ring: the epilogue reuses it
 
     // acc[i][j][r] = C[m][n], m = m0 + wm*128 + i*16 + (lane&15), n = n0 + wn*64 + j*16 + 4*(lane>>4) + r

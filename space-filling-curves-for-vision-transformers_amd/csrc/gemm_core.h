@@ -140,11 +140,11 @@ __device__ __forceinline__ void epilogue_vec(const sfcvit_gemm_args &g, int m, i
     if (g.dropout_p > 0.f) {
         const uint32_t th = drop_thresh(g.dropout_p);
         const float sc = 1.f / (1.f - g.dropout_p);
-        const uint64_t pair = uint64_t(m) * uint64_t((g.N + 1) >> 1) + uint64_t(n >> 1);
+        const uint32_t rk = drop_row_key(g.dropout_seed, uint64_t(m));
 #pragma unroll
         for (int q = 0; q < NV / 2; q++) {
             bool k0, k1;
-            drop_keep2(g.dropout_seed, pair + q, th, k0, k1);
+            drop_keep2(rk, uint32_t(n >> 1) + q, th, k0, k1);
             v[2 * q] = k0 ? v[2 * q] * sc : 0.f;
             v[2 * q + 1] = k1 ? v[2 * q + 1] * sc : 0.f;
         }

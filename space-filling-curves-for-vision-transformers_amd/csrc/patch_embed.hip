@@ -126,6 +126,7 @@ __global__ __launch_bounds__(THREADS, 2) void pe_fwd_kernel(const Geo g, const u
         }
         __syncthreads();
     }
+    mfma_fence();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(THREADS, 2) void pe_bwd_kernel(const Geo g, const u
         }
         __syncthreads();
     }
+    mfma_fence();
     store_partial(acc, slabs + size_t(blockIdx.z) * D * g.K, D, g.K, d0, f0, wm, wn, lane);
 }
 

@@ -142,11 +142,11 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                 }
                 *reinterpret_cast<u32x4 *>(dx + size_t(row) * D + c * 8) = pack8(o);
                 if (dx_drop) {
-                    const uint64_t pair0 = uint64_t(row) * uint64_t(D >> 1) + uint64_t(c * 4);
+                    const uint32_t rk = drop_row_key(drop_seed, uint64_t(row));
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         bool k0, k1;
-                        drop_keep2(drop_seed, pair0 + q, drop_th, k0, k1);
+                        drop_keep2(rk, uint32_t(c * 4 + q), drop_th, k0, k1);
                         o[2 * q] = k0 ? o[2 * q] * drop_sc : 0.f;
                         o[2 * q + 1] = k1 ? o[2 * q + 1] * drop_sc : 0.f;
                     }
@@ -278,11 +278,11 @@ __global__ __launch_bounds__(THREADS) void gelu_drop_kernel(const uint16_t *__re
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = gelu_erf(xv[j]);
         }
-        const uint64_t pair0 = uint64_t(row) * uint64_t(cols >> 1) + uint64_t(cv * 4);
+        const uint32_t rk = drop_row_key(seed, uint64_t(row));
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             bool k0, k1;
-            drop_keep2(seed, pair0 + q, th, k0, k1);
+            drop_keep2(rk, uint32_t(cv * 4 + q), th, k0, k1);
             o[2 * q] = k0 ? o[2 * q] * sc : 0.f;
             o[2 * q + 1] = k1 ? o[2 * q + 1] * sc : 0.f;
         }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(THREADS) void dropout_mask_kernel(uint16_t *__restr
         const int64_t row = i / ppr;
         const int c = int(i - row * ppr) * 2;
         bool k0, k1;
-        drop_keep2(seed, uint64_t(i), th, k0, k1);
+        drop_keep2(drop_row_key(seed, uint64_t(row)), uint32_t(c >> 1), th, k0, k1);
         out[row * cols + c] = k0 ? on : uint16_t(0);
         if (c + 1 < cols) out[row * cols + c + 1] = k1 ? on : uint16_t(0);
     }
