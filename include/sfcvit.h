@@ -139,6 +139,10 @@ int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);
 /* HOST: bytes of workspace sfcvit_gemm needs for this split (0 when splitk <= 1). */
 int64_t sfcvit_gemm_workspace(int M, int N, int splitk);
 
+/* dst[c, r] = src[r, c] (bf16; R, C, lds, ldd multiples of 8).  One transposed copy of a weight per
+ * step lets dX = dY W run with both operands k-contiguous (sfcvit_gemm's fastest layout). */
+int sfcvit_transpose(const void *src, int R, int C, int lds, void *dst, int ldd, void *stream);
+
 /* Column sums: out[n] = sum_m x[m, n] (bias gradients). x bf16 [M, ld]; out fp32 [N]. */
 int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *stream);
 
@@ -155,12 +159,15 @@ int sfcvit_layernorm_fwd(const void *x, const void *gamma, const void *beta, voi
 int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const float *rstd,
                          const void *gamma, const void *dx_add, void *dx, float *dgamma,
                          float *dbeta, int M, int D, void *ws, void *stream);
-/* Same, plus dx_drop[m, d] = keep(m, d) ? dx / (1 - p) : 0 (bf16): the gradient entering a sub-layer
- * whose output went through nn.Dropout(p) before the residual add (dropout1 / dropout2,
- * torch:nn/modules/transformer.py:953-957), mask regenerated from `seed`. */
+/* Same, plus (dx_drop != NULL) dx_drop[m, d] = keep(m, d) ? dx / (1 - p) : 0 (bf16): the gradient
+ * entering a sub-layer whose output went through nn.Dropout(p) before the residual add (dropout1 /
+ * dropout2, torch:nn/modules/transformer.py:953-957), mask regenerated from `seed`; and
+ * (dcol != NULL) dcol[d] = sum_m of that outgoing gradient (dx_drop if given, else dx), fp32 [D]: the
+ * bias gradient of the sub-layer's last Linear, for free in the same pass. */
 int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, const float *rstd,
                               const void *gamma, const void *dx_add, void *dx, void *dx_drop, float p,
-                              uint32_t seed, float *dgamma, float *dbeta, int M, int D, void *ws, void *stream);
+                              uint32_t seed, float *dgamma, float *dbeta, float *dcol, int M, int D,
+                              void *ws, void *stream);
 int64_t sfcvit_layernorm_bwd_ws(int M, int D);
 
 /* ------------------------------------------------------------------------

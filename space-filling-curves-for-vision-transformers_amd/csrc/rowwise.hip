@@ -90,19 +90,19 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                                                          const uint16_t *__restrict__ dx_add, uint16_t *__restrict__ dx,
                                                          uint16_t *__restrict__ dx_drop, float drop_p, uint32_t drop_seed,
                                                          float *__restrict__ partial, int M, int D) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [WAVES][2][D] fp32
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [WAVES][3][D] fp32
     const uint32_t drop_th = drop_thresh(drop_p);
     const float drop_sc = 1.f / (1.f - drop_p);
     float *red = reinterpret_cast<float *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D >> 3;
-    float g[VPL][8], dg[VPL][8], db[VPL][8];
+    float g[VPL][8], dg[VPL][8], db[VPL][8], dc[VPL][8];   // dc: column sums of the outgoing gradient
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         const int c = lane + 64 * i;
         if (c < nvec) unpack8(*reinterpret_cast<const u32x4 *>(gamma + c * 8), g[i]);
 #pragma unroll
-        for (int j = 0; j < 8; j++) dg[i][j] = db[i][j] = 0.f;
+        for (int j = 0; j < 8; j++) dg[i][j] = db[i][j] = dc[i][j] = 0.f;
     }
     for (int row = blockIdx.x * WAVES + wave; row < M; row += gridDim.x * WAVES) {
         const float mu = mean[row], rs = rstd[row];
@@ -141,6 +141,10 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                     for (int j = 0; j < 8; j++) o[j] += a[j];
                 }
                 *reinterpret_cast<u32x4 *>(dx + size_t(row) * D + c * 8) = pack8(o);
+                if (!dx_drop) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) dc[i][j] += o[j];
+                }
                 if (dx_drop) {
                     const uint32_t rk = drop_row_key(drop_seed, uint64_t(row));
 #pragma unroll
@@ -151,6 +155,8 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                         o[2 * q + 1] = k1 ? o[2 * q + 1] * drop_sc : 0.f;
                     }
                     *reinterpret_cast<u32x4 *>(dx_drop + size_t(row) * D + c * 8) = pack8(o);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) dc[i][j] += o[j];
                 }
             }
         }
@@ -161,44 +167,46 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
         if (c < nvec) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                red[(wave * 2 + 0) * D + c * 8 + j] = dg[i][j];
-                red[(wave * 2 + 1) * D + c * 8 + j] = db[i][j];
+                red[(wave * 3 + 0) * D + c * 8 + j] = dg[i][j];
+                red[(wave * 3 + 1) * D + c * 8 + j] = db[i][j];
+                red[(wave * 3 + 2) * D + c * 8 + j] = dc[i][j];
             }
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * D; c += THREADS) {
+    for (int c = threadIdx.x; c < 3 * D; c += THREADS) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; w++) s += red[w * 2 * D + c];
-        partial[size_t(blockIdx.x) * 2 * D + c] = s;
+        for (int w = 0; w < WAVES; w++) s += red[w * 3 * D + c];
+        partial[size_t(blockIdx.x) * 3 * D + c] = s;
     }
 }
 
-// Sum of the per-block partials: 32 columns x 8 partial-groups per block, coalesced 128-byte
-// row segments, fixed summation order (bitwise reproducible).
+// Sum of the per-block partials [nblocks][3][D] (dgamma | dbeta | column sums of the outgoing
+// gradient): 16 columns x 16 partial-groups per block, fixed summation order (bitwise reproducible).
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float *__restrict__ partial, float *__restrict__ dgamma,
-                                                    float *__restrict__ dbeta, int nblocks, int D) {
-    __shared__ float red[8][32];
-    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+                                                    float *__restrict__ dbeta, float *__restrict__ dcol, int nblocks, int D) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    if (c < 2 * D)
-        for (int b = grp; b < nblocks; b += 8) s += partial[size_t(b) * 2 * D + c];
+    if (c < 3 * D)
+        for (int b = grp; b < nblocks; b += 16) s += partial[size_t(b) * 3 * D + c];
     red[grp][cl] = s;
     __syncthreads();
-    if (grp == 0 && c < 2 * D) {
+    if (grp == 0 && c < 3 * D) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; k++) t += red[k][cl];
+        for (int k = 0; k < 16; k++) t += red[k][cl];
         if (c < D) dgamma[c] = t;
-        else dbeta[c - D] = t;
+        else if (c < 2 * D) dbeta[c - D] = t;
+        else if (dcol) dcol[c - 2 * D] = t;
     }
 }
 
 int ln_bwd_blocks(int M) {
     const int want = (M + WAVES - 1) / WAVES;
-    return want < 1024 ? want : 1024;
+    return want < 512 ? want : 512;
 }
 
 // ---------------------------------------------------------------------------
@@ -230,6 +238,40 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(const uint16_t *__restr
 #pragma unroll
         for (int r = 0; r < 8; r++) t += red[r][threadIdx.x];
         atomicAdd(out + c, t);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// bf16 matrix transpose: dst[c][r] = src[r][c], 64 x 64 tiles through LDS (16-byte global
+// accesses on both sides).  Used once per step per weight so that dX = dY W runs with both
+// operands k-contiguous (the layout the LDS-DMA GEMM is fastest on).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void transpose_kernel(const uint16_t *__restrict__ src, int R, int C, int lds,
+                                                            uint16_t *__restrict__ dst, int ldd) {
+    __shared__ uint16_t tile[64][66];                       // 66: odd dword stride, conflict-free column reads
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                           // 64 rows x 8 vectors
+        const int v = t + THREADS * i, r = v >> 3, cv = (v & 7) * 8;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (r0 + r < R && c0 + cv < C) val = *reinterpret_cast<const u32x4 *>(src + size_t(r0 + r) * lds + c0 + cv);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            tile[r][cv + 2 * j] = uint16_t(val[j]);
+            tile[r][cv + 2 * j + 1] = uint16_t(val[j] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int v = t + THREADS * i, c = v >> 3, rv = (v & 7) * 8;
+        if (c0 + c < C && r0 + rv < R) {
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = uint32_t(tile[rv + 2 * j][c]) | (uint32_t(tile[rv + 2 * j + 1][c]) << 16);
+            *reinterpret_cast<u32x4 *>(dst + size_t(c0 + c) * ldd + r0 + rv) = o;
+        }
     }
 }
 
@@ -465,13 +507,13 @@ extern "C" int sfcvit_layernorm_fwd(const void *x, const void *gamma, const void
 
 extern "C" int64_t sfcvit_layernorm_bwd_ws(int M, int D) {
     if (M <= 0 || D <= 0) return 0;
-    return int64_t(ln_bwd_blocks(M)) * 2 * D * int64_t(sizeof(float));
+    return int64_t(ln_bwd_blocks(M)) * 3 * D * int64_t(sizeof(float));
 }
 
 extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, const float *rstd,
                                          const void *gamma, const void *dx_add, void *dx, void *dx_drop, float p,
-                                         uint32_t seed, float *dgamma, float *dbeta, int M, int D, void *ws,
-                                         void *stream) {
+                                         uint32_t seed, float *dgamma, float *dbeta, float *dcol, int M, int D,
+                                         void *ws, void *stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !ws)
         return fail(SFCVIT_EINVAL, "layernorm_bwd: null pointer");
     if (M <= 0 || D <= 0 || D % 8 || D > 2048) return fail(SFCVIT_EINVAL, "layernorm_bwd: M=%d D=%d (D %% 8 == 0, D <= 2048)", M, D);
@@ -482,7 +524,7 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = ln_bwd_blocks(M);
     dim3 grid(nb), block(THREADS);
-    const size_t lds = size_t(WAVES) * 2 * D * sizeof(float);
+    const size_t lds = size_t(WAVES) * 3 * D * sizeof(float);
     const auto *dyp = static_cast<const uint16_t *>(dy);
     const auto *xp = static_cast<const uint16_t *>(x);
     const auto *gp = static_cast<const uint16_t *>(gamma);
@@ -494,14 +536,14 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
     else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
     if (int rc = check_launch("layernorm_bwd")) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 31) / 32), dim3(256), 0, s, part, dgamma, dbeta, nb, D);
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((3 * D + 15) / 16), dim3(256), 0, s, part, dgamma, dbeta, dcol, nb, D);
     return check_launch("layernorm_bwd_reduce");
 }
 
 extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const float *rstd,
                                     const void *gamma, const void *dx_add, void *dx, float *dgamma, float *dbeta,
                                     int M, int D, void *ws, void *stream) {
-    return sfcvit_layernorm_bwd_drop(dy, x, mean, rstd, gamma, dx_add, dx, nullptr, 0.f, 0u, dgamma, dbeta, M, D, ws, stream);
+    return sfcvit_layernorm_bwd_drop(dy, x, mean, rstd, gamma, dx_add, dx, nullptr, 0.f, 0u, dgamma, dbeta, nullptr, M, D, ws, stream);
 }
 
 extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *stream) {
@@ -519,6 +561,16 @@ extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, vo
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(THREADS), 0, s,
                        static_cast<const uint16_t *>(x), M, N, ld, rpb, out);
     return check_launch("colsum");
+}
+
+extern "C" int sfcvit_transpose(const void *src, int R, int C, int lds, void *dst, int ldd, void *stream) {
+    if (!src || !dst) return fail(SFCVIT_EINVAL, "transpose: null pointer");
+    if (R <= 0 || C <= 0 || R % 8 || C % 8 || lds % 8 || ldd % 8 || lds < C || ldd < R)
+        return fail(SFCVIT_EINVAL, "transpose: R=%d C=%d lds=%d ldd=%d (multiples of 8)", R, C, lds, ldd);
+    if (!aligned16(src) || !aligned16(dst)) return fail(SFCVIT_EINVAL, "transpose: alignment");
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(THREADS), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(src), R, C, lds, static_cast<uint16_t *>(dst), ldd);
+    return check_launch("transpose");
 }
 
 extern "C" int sfcvit_gelu_fwd(const void *x, void *y, int64_t n, void *stream) {

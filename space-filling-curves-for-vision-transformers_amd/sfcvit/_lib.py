@@ -60,6 +60,7 @@ SIGNATURES = {
     "sfcvit_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
     "sfcvit_gemm_workspace": (c_int64, [c_int, c_int, c_int]),
     "sfcvit_patch_embed_workspace": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sfcvit_transpose": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sfcvit_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sfcvit_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_float, c_void_p]),
@@ -67,7 +68,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sfcvit_layernorm_bwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_float, ctypes.c_uint32, c_void_p, c_void_p,
-                                          c_int, c_int, c_void_p, c_void_p]),
+                                          c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sfcvit_layernorm_bwd_ws": (c_int64, [c_int, c_int]),
     "sfcvit_gelu_drop_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p]),
     "sfcvit_gelu_drop_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p]),

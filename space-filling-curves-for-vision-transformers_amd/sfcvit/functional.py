@@ -85,7 +85,7 @@ class _Linear(Function):
             dy2 = torch.where(aux > 0, dy2, torch.zeros_like(dy2))
         elif ctx.act == ops.ACT_GELU:
             dy2 = ops.gelu_bwd(dy2, aux)
-        dx = ops.gemm(dy2, w, b_kmajor=True).view(ctx.shape)
+        dx = ops.gemm_dx(dy2, w).view(ctx.shape)
         return dx, _wgrad(dy2, x2), (_bgrad(dy2) if ctx.has_bias else None), None
 
 
@@ -147,9 +147,9 @@ class _Mixer(Function):
         x2, mean, rstd, z, u, h, ln_w, w1, w2 = ctx.saved_tensors
         dy2 = _c(dy).view(-1, dy.shape[-1])
         dw2, db2 = _wgrad(dy2, h), _bgrad(dy2)
-        du = ops.gemm(dy2, w2, b_kmajor=True, aux_in=u, dact=ops.ACT_GELU)
+        du = ops.gemm_dx(dy2, w2, aux_in=u, dact=ops.ACT_GELU)
         dw1, db1 = _wgrad(du, z), _bgrad(du)
-        dz = ops.gemm(du, w1, b_kmajor=True)
+        dz = ops.gemm_dx(du, w1)
         dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w, dx_add=dy2)
         return dx.view(dy.shape), dg.to(_BF16), dbeta.to(_BF16), dw1, db1, dw2, db2, None
 
@@ -191,27 +191,29 @@ class _EncoderLayer(Function):
         p = ctx.p
         sa, s1_, sf, s2_ = ctx.seeds
         dy2 = _c(dy).view(B * N, D)
+        # LayerNorm backward also returns the column sums of the gradient it hands to the sub-layer:
+        # that is the bias gradient of linear2 / out_proj, for free in the same pass.
         if p > 0:
-            ds2, dg2, dbt2, df = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w, drop_p=p, drop_seed=s2_)
+            ds2, dg2, dbt2, df, db2 = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w, drop_p=p, drop_seed=s2_, want_colsum=True)
         else:
-            ds2, dg2, dbt2 = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w)
+            ds2, dg2, dbt2, db2 = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w, want_colsum=True)
             df = ds2
-        dw2, db2 = _wgrad(df, h), _bgrad(df)
+        dw2, db2 = _wgrad(df, h), db2.to(_BF16)
         # h is stored after relu + dropout: (h > 0) is the joint mask, 1/(1-p) the dropout scale
-        dh = ops.gemm(df, w2, b_kmajor=True, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p))
+        dh = ops.gemm_dx(df, w2, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p))
         dw1, db1 = _wgrad(dh, x1), _bgrad(dh)
-        dx1 = ops.gemm(dh, w1, b_kmajor=True, residual=ds2)
+        dx1 = ops.gemm_dx(dh, w1, residual=ds2)
         if p > 0:
-            ds1, dg1, dbt1, da = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w, drop_p=p, drop_seed=s1_)
+            ds1, dg1, dbt1, da, dbo = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w, drop_p=p, drop_seed=s1_, want_colsum=True)
         else:
-            ds1, dg1, dbt1 = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w)
+            ds1, dg1, dbt1, dbo = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w, want_colsum=True)
             da = ds1
         o2 = o.view(B * N, D)
-        dwo, dbo = _wgrad(da, o2), _bgrad(da)
-        do = ops.gemm(da, out_w, b_kmajor=True)
+        dwo, dbo = _wgrad(da, o2), dbo.to(_BF16)
+        do = ops.gemm_dx(da, out_w)
         dqkv = ops.attention_bwd(qkv.view(B, N, 3 * D), o, lse, do.view(B, N, D), ctx.n_heads, p, sa).view(B * N, 3 * D)
         dwi, dbi = _wgrad(dqkv, x2), _bgrad(dqkv)
-        dx = ops.gemm(dqkv, in_w, b_kmajor=True, residual=ds1)
+        dx = ops.gemm_dx(dqkv, in_w, residual=ds1)
         return (dx.view(B, N, D), dwi, dbi, dwo, dbo, dg1.to(_BF16), dbt1.to(_BF16), dw1, db1, dw2, db2,
                 dg2.to(_BF16), dbt2.to(_BF16), None, None, None, None)
 
@@ -262,13 +264,13 @@ class _Head(Function):
         dl[:, :C] = dlogits
         dwc = ops.gemm(dl, a, a_kmajor=True, b_kmajor=True)[:C]
         dbc = ops.colsum(dl)[:C].to(_BF16)
-        da = ops.gemm(dl, wc_p, b_kmajor=True)                      # [B, O]
+        da = ops.gemm_dx(dl, wc_p)                      # [B, O]
         dy1 = ops.gelu_drop_bwd(da, y1, ctx.p, ctx.seed) if ctx.p > 0 else ops.gelu_bwd(da, y1)
         h2 = h.view(B, N * R)
         dwseq = ops.gemm(dy1, h2, a_kmajor=True, b_kmajor=True).view(O, N, R)
         dh = ops.gemm(dy1, w_seq.view(O, N * R), b_kmajor=True).view(B * N, R)
         dwemb = _wgrad(dh, z)
-        dz = ops.gemm(dh, w_emb, b_kmajor=True)
+        dz = ops.gemm_dx(dh, w_emb)
         dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w)
         return dx.view(B, N, D), dg.to(_BF16), dbeta.to(_BF16), dwemb, dwseq, dwc, dbc, None, None, None
 

@@ -150,6 +150,26 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
     return (c, aux) if want_aux else c
 
 
+def transpose(x):
+    """[R, C] bf16 -> contiguous [C, R]."""
+    _rows2d(x, _BF16, "transpose x")
+    R, C = x.shape
+    out = torch.empty((C, R), device=x.device, dtype=_BF16)
+    check(lib.sfcvit_transpose(_p(x), R, C, x.stride(0), _p(out), R, _stream()), "sfcvit_transpose")
+    return out
+
+
+def gemm_dx(dy, w, **kw):
+    """dX[M, in] = dY[M, out] . W[out, in] (+ epilogue).  When the shape is eligible for the LDS-DMA
+    kernel, W is transposed once (a few MB) so that both operands are k-contiguous; otherwise W is
+    read k-major in place by the generic kernel."""
+    M, K = dy.shape
+    N = w.shape[1]
+    if M % 256 == 0 and N % 128 == 0 and K % 32 == 0 and K % 8 == 0:
+        return gemm(dy, transpose(w), **kw)
+    return gemm(dy, w, b_kmajor=True, **kw)
+
+
 def colsum(x):
     _rows2d(x, _BF16, "colsum x")
     out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
@@ -171,8 +191,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0):
-    """-> dx, dgamma, dbeta (and dx_drop = dropout-masked dx when drop_p > 0, as 4th value)."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0, want_colsum=False):
+    """-> dx, dgamma, dbeta [, dx_drop when drop_p > 0] [, colsum of the outgoing gradient (dx_drop if
+    drop_p > 0 else dx) when want_colsum]."""
     _need(dy, _BF16, "layernorm dy", 2)
     _need(x, _BF16, "layernorm x", 2)
     M, D = x.shape
@@ -183,10 +204,12 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0
     ws = torch.empty(lib.sfcvit_layernorm_bwd_ws(M, D), device=x.device, dtype=torch.uint8)
     if dx_add is not None:
         _need(dx_add, _BF16, "layernorm dx_add", 2)
+    dcol = torch.empty(D, device=x.device, dtype=torch.float32) if want_colsum else None
     check(lib.sfcvit_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_add), _p(dx), _p(dx_drop),
-                                        drop_p, drop_seed, _p(dg), _p(db), M, D, _p(ws), _stream()),
+                                        drop_p, drop_seed, _p(dg), _p(db), _p(dcol), M, D, _p(ws), _stream()),
           "sfcvit_layernorm_bwd")
-    return (dx, dg, db, dx_drop) if drop_p > 0 else (dx, dg, db)
+    out = (dx, dg, db) + ((dx_drop,) if drop_p > 0 else ()) + ((dcol,) if want_colsum else ())
+    return out
 
 
 # ----------------------------------------------------------------------------

@@ -74,6 +74,8 @@ def test_layernorm_bwd_dropped_output(ops):
     mask = ops.dropout_mask(M, D, p, seed).float()
     close(dxd, dx.float() * mask, rel=1 / 100, abs_scale=1e-3)
     assert torch.equal(dxd == 0, (mask == 0) | (dx == 0))
+    *_, dcol = ops.layernorm_bwd(dy, x, mean, rstd, gamma, drop_p=p, drop_seed=seed, want_colsum=True)
+    close(dcol, dxd.float().sum(0), rel=5e-3, abs_scale=5e-3)          # column sums of the masked gradient
 
 
 def test_gelu_dropout(ops):

@@ -163,6 +163,9 @@ def test_layernorm(ops, M, D):
     close(db, bfl.grad, rel=2e-3, abs_scale=2e-3)
     dx2, _, _ = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=add)
     close(dx2, xf.grad + add.float())
+    dx3, dg3, db3, dcol = ops.layernorm_bwd(dy, x, mean, rstd, gamma, want_colsum=True)
+    assert torch.equal(dx3, dx) and torch.equal(dg3, dg)
+    close(dcol, dx.float().sum(0), rel=1e-2, abs_scale=1e-2)          # bias gradient of the sub-layer (fp32 sums of the un-rounded dx)
 
 
 def test_colsum(ops):
@@ -277,3 +280,16 @@ def test_adamw_and_clip(ops):
                        weight_decay=5e-5, max_norm=1.0, step=step)
         assert torch.allclose(master, ref.detach(), atol=1e-6, rtol=1e-5)
         assert torch.equal(param, bf(master))
+
+
+def test_transpose_and_gemm_dx(ops):
+    g = torch.Generator(device="cuda").manual_seed(21)
+    w = bf(torch.randn(2304, 768, device="cuda", generator=g))
+    assert torch.equal(ops.transpose(w), w.t().contiguous())
+    v = w[:, 128:392]                                   # strided view, 264 columns
+    assert torch.equal(ops.transpose(v), v.t().contiguous())
+    dy = bf(torch.randn(512, 2304, device="cuda", generator=g))
+    res = bf(torch.randn(512, 768, device="cuda", generator=g))
+    ref = dy.float() @ w.float() + res.float()
+    close(ops.gemm_dx(dy, w, residual=res), ref)                         # LDS-DMA kernel on W^T
+    close(ops.gemm_dx(dy[:200], w, residual=res[:200]), ref[:200])       # generic kernel, W read k-major
