@@ -104,10 +104,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # Rehearsal knobs (single-GPU box): SFCVIT_DIST_BACKEND=gloo + SFCVIT_FORCE_DEVICE=0 run N ranks of the
+    # real data-parallel code path on one card; the driver's N-GPU runs use neither.
+    backend = os.environ.get("SFCVIT_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("SFCVIT_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from sfcvit import ops
     from sfcvit.training import FusedAdamW, GradReducer, mixup_soft_targets, train_step
