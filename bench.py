@@ -179,8 +179,19 @@ def main():
             dom = max(kern, key=lambda k: kern[k]["ms_total"])
             r = kern[dom]
             ach = r["work_total"] / (r["ms_total"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            # rocprofv3 symbol of the launches behind each timing key (for the committed profiles/ summaries)
+            symbol = {"gemm y=x.W^T (k-contig, k-contig)": "gemm256_kernel<false,false,128,false>",
+                      "gemm dW=dy^T.x (k-major, k-major)": "gemm_kernel<true,true,false>",
+                      "gemm dx=dy.W (k-contig, k-major)": "gemm_kernel<false,true,false>"}.get(dom, dom)
+            traffic = None                          # PMC counters cannot be read live: offline passes, see profiles/traffic.json
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    traffic = json.load(f)["kernels"].get(symbol, {}).get("traffic_bytes")
+            except (OSError, ValueError, KeyError):
+                pass
+            out["roofline"] = {"kernel": dom, "rocprof_symbol": symbol, "bound": "mfma", "achieved": round(ach, 2),
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                               "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md)" if traffic else None,
                                "launches": r["launches"], "avg_launch_ms": round(r["ms_avg"], 4),
                                "flops_per_launch": r["work_total"] / r["launches"]}
             out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": round(v["ms_total"] / args.steps, 3),
