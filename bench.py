@@ -95,6 +95,9 @@ def main():
                     help="encoder dropout (reference default 0.1; the head then uses the reference's 0.5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--time-all-kernels", action="store_true",
+                    help="HIP-event pairs around every op (default: only the GEMM families, the dominant kernels; "
+                         "700 event pairs per step cost ~2.5 %% of throughput)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
@@ -139,7 +142,7 @@ def main():
     for _ in range(args.warmup):
         loss = train_step(model, images, targets, opt, reducer=reducer)
     if rank == 0 and not args.no_kernel_timing:
-        ops.TIMER = ops.KernelTimer()
+        ops.TIMER = ops.KernelTimer(None if args.time_all_kernels else "gemm ")
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

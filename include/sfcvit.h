@@ -133,6 +133,8 @@ typedef struct sfcvit_gemm_args {
     float dropout_p;       /* > 0: after act, before residual: v = keep(m, n) ? v / (1 - p) : 0 (nn.Dropout, training) */
     uint32_t dropout_seed;
     float dact_scale;      /* multiplies v together with dact (0 = 1): 1/(1-p) of a dropout that followed the ReLU */
+    int32_t row_offset;    /* dropout mask row of C row m is m + row_offset (a GEMM computed as row slices
+                              keeps one mask) */
 } sfcvit_gemm_args;
 
 int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);

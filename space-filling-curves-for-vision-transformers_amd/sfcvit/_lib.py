@@ -29,7 +29,8 @@ class GemmArgs(ctypes.Structure):
                 ("a_kmajor", c_int32), ("b_kmajor", c_int32), ("act", c_int32), ("dact", c_int32),
                 ("c_is_f32", c_int32), ("splitk", c_int32), ("workspace", c_void_p),
                 ("workspace_bytes", c_int64), ("force_generic", c_int32),
-                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("dact_scale", c_float)]
+                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("dact_scale", c_float),
+                ("row_offset", c_int32)]
 
 
 class AttnArgs(ctypes.Structure):

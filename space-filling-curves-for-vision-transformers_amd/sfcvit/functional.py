@@ -37,6 +37,41 @@ def _wgrad(dy2, x2):
     return ops.gemm(dy2, x2, a_kmajor=True, b_kmajor=True)
 
 
+class _SideStream:
+    """Weight-gradient GEMMs do not feed the rest of backward, so they run on a second HIP stream
+    next to the dX chain: the tail round of one kernel (1176 tiles on 512 workgroup slots leave the
+    third round 30 % full) could be filled with workgroups of the other.  MEASURED SLOWER on MI355X
+    (5 110 vs 5 210 img/s, A/B in one process): the two GEMMs evict each other's panels from L2.
+    Kept as an option (SFCVIT_SIDE_STREAM=1), off by default."""
+    _streams = {}
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        key = (device.index, self.main.cuda_stream)
+        if key not in _SideStream._streams:
+            _SideStream._streams[key] = torch.cuda.Stream(device)
+        self.side = _SideStream._streams[key]
+
+    def run(self, fn, *tensors):
+        """fn() on the side stream after everything issued so far on the main stream."""
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        for t in tensors:                       # inputs allocated on the main stream, read on the side stream
+            t.record_stream(self.side)
+        return out
+
+    def join(self, *outs):
+        self.main.wait_stream(self.side)
+        for t in outs:                          # allocated on the side stream, consumed on the main stream
+            if t is not None:
+                t.record_stream(self.main)
+
+
+import os as _os
+SIDE_STREAM_WGRAD = _os.environ.get("SFCVIT_SIDE_STREAM", "0") == "1"
+
+
 def _bgrad(dy2):
     return ops.colsum(dy2).to(_BF16)
 
@@ -191,6 +226,8 @@ class _EncoderLayer(Function):
         p = ctx.p
         sa, s1_, sf, s2_ = ctx.seeds
         dy2 = _c(dy).view(B * N, D)
+        ss = _SideStream(dy2.device) if SIDE_STREAM_WGRAD else None
+        wg = (lambda a_, b_: ss.run(lambda: _wgrad(a_, b_), a_, b_)) if ss else _wgrad
         # LayerNorm backward also returns the column sums of the gradient it hands to the sub-layer:
         # that is the bias gradient of linear2 / out_proj, for free in the same pass.
         if p > 0:
@@ -198,10 +235,10 @@ class _EncoderLayer(Function):
         else:
             ds2, dg2, dbt2, db2 = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w, want_colsum=True)
             df = ds2
-        dw2, db2 = _wgrad(df, h), db2.to(_BF16)
+        dw2, db2 = wg(df, h), db2.to(_BF16)
         # h is stored after relu + dropout: (h > 0) is the joint mask, 1/(1-p) the dropout scale
         dh = ops.gemm_dx(df, w2, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p))
-        dw1, db1 = _wgrad(dh, x1), _bgrad(dh)
+        dw1, db1 = wg(dh, x1), _bgrad(dh)
         dx1 = ops.gemm_dx(dh, w1, residual=ds2)
         if p > 0:
             ds1, dg1, dbt1, da, dbo = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w, drop_p=p, drop_seed=s1_, want_colsum=True)
@@ -209,11 +246,13 @@ class _EncoderLayer(Function):
             ds1, dg1, dbt1, dbo = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w, want_colsum=True)
             da = ds1
         o2 = o.view(B * N, D)
-        dwo, dbo = _wgrad(da, o2), dbo.to(_BF16)
+        dwo, dbo = wg(da, o2), dbo.to(_BF16)
         do = ops.gemm_dx(da, out_w)
         dqkv = ops.attention_bwd(qkv.view(B, N, 3 * D), o, lse, do.view(B, N, D), ctx.n_heads, p, sa).view(B * N, 3 * D)
-        dwi, dbi = _wgrad(dqkv, x2), _bgrad(dqkv)
+        dwi, dbi = wg(dqkv, x2), _bgrad(dqkv)
         dx = ops.gemm_dx(dqkv, in_w, residual=ds1)
+        if ss:
+            ss.join(dw2, dw1, dwo, dwi)
         return (dx.view(B, N, D), dwi, dbi, dwo, dbo, dg1.to(_BF16), dbt1.to(_BF16), dw1, db1, dw2, db2,
                 dg2.to(_BF16), dbt2.to(_BF16), None, None, None, None)
 

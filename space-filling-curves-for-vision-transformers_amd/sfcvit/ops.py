@@ -20,10 +20,13 @@ class KernelTimer:
     """Optional per-launch timing with HIP events on the launching stream (bench.py's roofline
     leg).  Set `ops.TIMER = KernelTimer()`; every wrapper below then brackets its launch."""
 
-    def __init__(self):
+    def __init__(self, only_prefix=None):
         self.records = {}
+        self.only_prefix = only_prefix      # time only keys with this prefix (an event pair costs ~1 us of stream time)
 
     def launch(self, key, work, fn):
+        if self.only_prefix and not key.startswith(self.only_prefix):
+            return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn()
@@ -113,7 +116,7 @@ def next_seed():
 
 def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, residual=None,
          aux_in=None, dact=ACT_NONE, want_aux=False, out_f32=False, splitk=None, force_generic=False,
-         dropout_p=0.0, dropout_seed=0, dact_scale=1.0, out=None):
+         dropout_p=0.0, dropout_seed=0, dact_scale=1.0, out=None, row_offset=0):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  a: [M,K] (or [K,M] if a_kmajor),
     b: [N,K] (or [K,N] if b_kmajor), bf16.  Returns C (and the pre-activation if want_aux)."""
     _rows2d(a, _BF16, "gemm a")
@@ -147,6 +150,7 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
     args.a_kmajor, args.b_kmajor = int(a_kmajor), int(b_kmajor)
     args.act, args.dact, args.c_is_f32 = act, dact, int(out_f32)
     args.dropout_p, args.dropout_seed, args.dact_scale = dropout_p, dropout_seed, dact_scale
+    args.row_offset = row_offset
     plain = (bias is None and residual is None and aux_in is None and not want_aux and act == 0 and dact == 0
              and dropout_p == 0.0)
     if splitk is None:

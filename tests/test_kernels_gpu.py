@@ -293,3 +293,17 @@ def test_transpose_and_gemm_dx(ops):
     ref = dy.float() @ w.float() + res.float()
     close(ops.gemm_dx(dy, w, residual=res), ref)                         # LDS-DMA kernel on W^T
     close(ops.gemm_dx(dy[:200], w, residual=res[:200]), ref[:200])       # generic kernel, W read k-major
+
+
+def test_gemm_row_slices_share_one_dropout_mask(ops):
+    # a GEMM computed as two row slices (row_offset) reproduces the single-launch dropout mask
+    g = torch.Generator(device="cuda").manual_seed(31)
+    M, N, K = 1024, 256, 64
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g))
+    kw = dict(act=ops.ACT_RELU, dropout_p=0.1, dropout_seed=99)
+    full = ops.gemm(a, w, **kw)
+    lo = ops.gemm(a[:512], w, **kw)
+    hi = ops.gemm(a[512:], w, row_offset=512, **kw)
+    assert torch.equal(full, torch.cat([lo, hi]))
+    assert torch.equal(full, ops.gemm(a, w, force_generic=1, **kw))
