@@ -49,7 +49,11 @@ enum sfcvit_curve {
     SFCVIT_CURVE_Z = 1,       /* :134-165 */
     SFCVIT_CURVE_MOORE = 2,   /* :205-251 */
     SFCVIT_CURVE_PEANO = 3,   /* :74-131  */
-    SFCVIT_CURVE_RASTER = 4   /* identity order (RasterScan1DEmbedding, zigzag_embedding1D.py:30-39) */
+    SFCVIT_CURVE_RASTER = 4,  /* identity order (RasterScan1DEmbedding, zigzag_embedding1D.py:30-39) */
+    SFCVIT_CURVE_SPIRAL = 5,  /* inward spiral from the bottom-left cell: OnionEmbedding1D.onion_indices,
+                                 src/tokenizers/_1D/onion_embedding1D.py:35-53 = multiscale/multi_onion.py:68-87 */
+    SFCVIT_CURVE_HILBERT_T = 6 /* the private generator of _2D/HilbertEmbedding (src/tokenizers/_2D/
+                                 hilbert_embedding.py:30-78): Hilbert without the (x,y) swap; n a power of two */
 };
 
 /* HOST. embed_and_prune_sfc(curve, n, n) (space_filling_curves.py:471-491) as the
@@ -85,7 +89,8 @@ typedef struct sfcvit_patch_embed_args {
     void *dbias;        /* bwd: out [D] fp32 (NULL = skip) */
     void *workspace;    /* sfcvit_patch_embed_workspace(...) bytes, 16-byte aligned */
     int64_t workspace_bytes;
-    int32_t B, C, HW, N, P, D;
+    int32_t B, C, HW, N, P, D; /* N*P = H*W; D a multiple of 8; P*C arbitrary (padded to 8 inside; the
+                                  vectorised table reads need P % 8 == 0, other P take a scalar gather) */
     int32_t x_is_bf16;
 } sfcvit_patch_embed_args;
 
@@ -145,8 +150,11 @@ int64_t sfcvit_gemm_workspace(int M, int N, int splitk);
  * step lets dX = dY W run with both operands k-contiguous (sfcvit_gemm's fastest layout). */
 int sfcvit_transpose(const void *src, int R, int C, int lds, void *dst, int ldd, void *stream);
 
-/* Column sums: out[n] = sum_m x[m, n] (bias gradients). x bf16 [M, ld]; out fp32 [N]. */
-int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *stream);
+/* Column sums: out[n] = sum_m x[m, n] (bias gradients). x bf16 [M, ld]; out fp32 [N] (overwritten).
+ * Two passes through `workspace` (sfcvit_colsum_workspace bytes, HOST query) instead of float atomics, so the
+ * result is bit-reproducible from run to run. */
+int64_t sfcvit_colsum_workspace(int M, int N);
+int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * LayerNorm (biased variance, affine) -- nn.LayerNorm at norm1/norm2
@@ -215,8 +223,10 @@ int sfcvit_dropout_mask(void *out, int64_t rows, int cols, float p, uint32_t see
 int sfcvit_soft_ce(const void *logits, const float *targets, float *loss_rows, void *dlogits,
                    int B, int C, int ld, float gscale, void *stream);
 
-/* Sum of squares of a bf16 (is_f32 = 0) or fp32 buffer, accumulated into *out (fp32, device). */
-int sfcvit_sumsq_accum(const void *g, int64_t n, int is_f32, float *out, void *stream);
+/* Sum of squares of a bf16 (is_f32 = 0) or fp32 buffer, accumulated into *out (fp32, device).  Block partials
+ * go through `workspace` (SFCVIT_SUMSQ_WORKSPACE_BYTES, device) and are added in a fixed order: reproducible. */
+#define SFCVIT_SUMSQ_WORKSPACE_BYTES 4096
+int sfcvit_sumsq_accum(const void *g, int64_t n, int is_f32, float *out, void *workspace, void *stream);
 
 /* Fused clip_grad_norm_ + AdamW step (src/training/train.py:165-166, main.py:288-289) on a
  * flat buffer.  clip coefficient = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) is computed on the

@@ -26,3 +26,49 @@ MODEL_CASES = {
 CURVE_SMALL_N = (2, 4, 8, 14, 16, 24, 32)
 CURVE_SHA_N = (224, 384)
 CURVE_KINDS = ("hilbert", "z", "moore", "peano")
+
+# name -> (img_size, in_channels, patch_size_list, embed_dim, curve, batch): hierarchical tokenizers
+HIER_CASES = {
+    "hier_morton32": (32, 3, [16, 4, 1], 64, "z", 3),       # the shape of the reference's main.py:269-274 default
+    "hier_hilbert32_resample": (32, 3, [4, 4], 32, "hilbert", 2),   # 256 and 64 tokens: exercises the linear resampling
+}
+
+# name -> (reference module, class, ctor args, kind, batch): the remaining tokenizers.
+#   kind = ("grouped", curve, p, g, buffer)       Linear over g pre-patches of p x p pixels in `curve` order
+#        | ("conv", curve, p)                     Conv2d(kernel = stride = p) patches visited in `curve` order
+#        | ("hier", curve, [g...], buffer)        hierarchical wrapper over grouped levels
+TOKENIZER_CASES = {
+    "moore32_1d": ("src.tokenizers._1D.moore_embedding1D", "MooreEmbedding1D", (32, 64, 3, 48),
+                   ("grouped", "moore", 1, 64, "moore_indices:rc"), 2),
+    "peano27_1d": ("src.tokenizers._1D.peano_embedding1D", "PeanoEmbedding1D", (27, 81, 3, 40),
+                   ("grouped", "peano", 1, 81, "peano_indices:rc"), 2),
+    "peano32_1d": ("src.tokenizers._1D.peano_embedding1D", "PeanoEmbedding1D", (32, 256, 3, 32),
+                   ("grouped", "peano", 1, 256, "peano_indices:rc"), 2),
+    "onion32_1d": ("src.tokenizers._1D.onion_embedding1D", "OnionEmbedding1D", (32, 256, 3, 64),
+                   ("grouped", "spiral", 1, 256, None), 2),
+    "onion14_1d": ("src.tokenizers._1D.onion_embedding1D", "OnionEmbedding1D", (14, 49, 3, 32),
+                   ("grouped", "spiral", 1, 49, None), 3),
+    "onion32_p2g16": ("src.tokenizers.multiscale.multi_onion", "OnionEmbedding1D", (32, 2, 16, 3, 64),
+                      ("grouped", "spiral", 2, 16, "onion_indices"), 2),
+    "raster32_p4g4": ("src.tokenizers.multiscale.multi_zigzag", "RasterScan1DGroupedEmbedding", (32, 4, 4, 3, 64),
+                      ("grouped", "raster", 4, 4, None), 2),
+    "zigzag64_p16": ("src.tokenizers._2D.zigzag_embedding", "ZigzagEmbedding", (64, 16, 3, 96),
+                     ("conv", "raster", 16), 2),
+    "zigzag28_p4": ("src.tokenizers._2D.zigzag_embedding", "ZigzagEmbedding", (28, 4, 3, 32),
+                    ("conv", "raster", 4), 2),
+    "hilbert2d_32_p4": ("src.tokenizers._2D.hilbert_embedding", "HilbertEmbedding", (32, 4, 3, 64),
+                        ("conv", "hilbert_t", 4), 2),
+    "random2d_32_p8": ("src.tokenizers._2D.random_embedding", "RandomEmbedding", (32, 8, 3, 32),
+                       ("conv", "randperm", 8), 2),
+    "hier_moore32": ("src.tokenizers.multiscale.multi_moore", "HierarchicalMooreEmbedding", (32, 3, [16, 4], 32),
+                     ("hier", "moore", [16, 4], "sfc_indices"), 2),
+    "hier_peano27": ("src.tokenizers.multiscale.multi_peano", "HierarchicalPeanoEmbedding", (27, 3, [9], 32),
+                     ("hier", "peano", [9], "sfc_indices"), 2),
+    "hier_onion32": ("src.tokenizers.multiscale.multi_onion", "HierarchicalOnionEmbedding", (32, 3, [16, 4, 1], 32),
+                     ("hier", "spiral", [16, 4, 1], "onion_indices"), 2),
+    "hier_raster32": ("src.tokenizers.multiscale.multi_zigzag", "HierarchicalRasterScanEmbedding", (32, 3, [4, 4], 32),
+                      ("hier", "raster", [4, 4], None), 2),
+}
+RANDPERM_SEED = 1234       # torch.manual_seed before RandomEmbedding.forward (it draws torch.randperm on the CPU)
+SPIRAL_N = (1, 2, 3, 4, 7, 14, 32)
+HILBERT_T_N = (1, 2, 4, 8, 16, 32)

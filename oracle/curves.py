@@ -26,6 +26,9 @@ def _load():
         _lib.oracle_embed_and_prune_sfc.restype = ctypes.c_int64
         _lib.oracle_embed_and_prune_sfc.argtypes = [
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        for fn in (_lib.oracle_spiral_flat, _lib.oracle_hilbert2d_flat):
+            fn.restype = ctypes.c_int64
+            fn.argtypes = [ctypes.c_int, ctypes.c_void_p]
     return _lib
 
 
@@ -47,5 +50,15 @@ def flat_table(kind, n):
     (RasterScan1DEmbedding has no table, zigzag_embedding1D.py:30-39)."""
     if kind == "raster":
         return np.arange(n * n, dtype=np.int64)
+    if kind == "spiral":        # OnionEmbedding1D.onion_indices (onion_embedding1D.py:35-53), any n
+        out = np.zeros(n * n, dtype=np.int64)
+        _load().oracle_spiral_flat(n, out.ctypes.data)
+        return out
+    if kind == "hilbert_t":     # _2D/HilbertEmbedding._get_hilbert_indices (hilbert_embedding.py:30-45), n = 2^k
+        out = np.zeros(n * n, dtype=np.int64)
+        cnt = _load().oracle_hilbert2d_flat(n, out.ctypes.data)
+        if cnt != n * n:
+            raise ValueError(f"hilbert_t: grid {n} is not a power of two")
+        return out
     ij = embed_and_prune_sfc(kind, n, n)
     return ij[:, 0] * n + ij[:, 1]

@@ -18,6 +18,9 @@
  *   onion_curve          src/curves/space_filling_curves.py:9-71
  *   grid_size            src/curves/space_filling_curves.py:458-468
  *   embed_and_prune_sfc  src/curves/space_filling_curves.py:471-491
+ *   spiral walk          src/tokenizers/_1D/onion_embedding1D.py:35-53
+ *                        (= src/tokenizers/multiscale/multi_onion.py:68-87)
+ *   _2D Hilbert indices  src/tokenizers/_2D/hilbert_embedding.py:30-78
  */
 #include <math.h>
 #include <stdint.h>
@@ -256,4 +259,45 @@ int64_t oracle_embed_and_prune_sfc(int kind, int width, int height, int64_t *out
     }
     pts_free(&p);
     return cnt;
+}
+
+/*
+ * onion_embedding1D.py:35-53: walk from the bottom-left cell, directions right, up, left, down, turning when
+ * the next cell is outside or already visited.  Writes the flat indices r*n+c; returns n*n.
+ */
+int64_t oracle_spiral_flat(int n, int64_t *out) {
+    static const int di[4] = {0, -1, 0, 1}, dj[4] = {1, 0, -1, 0};
+    char *seen = (char *)calloc((size_t)n * n, 1);
+    int i = n - 1, j = 0, d = 0;
+    for (int64_t t = 0; t < (int64_t)n * n; t++) {
+        out[t] = (int64_t)i * n + j;
+        seen[(size_t)i * n + j] = 1;
+        int ni = i + di[d], nj = j + dj[d];
+        if (0 <= ni && ni < n && 0 <= nj && nj < n && !seen[(size_t)ni * n + nj]) {
+            i = ni;
+            j = nj;
+        } else {
+            d = (d + 1) % 4;
+            i += di[d];
+            j += dj[d];
+        }
+    }
+    free(seen);
+    return (int64_t)n * n;
+}
+
+/*
+ * _2D/hilbert_embedding.py:40-45: order = int(log2(grid)); points of the raw recursion on the unit square
+ * (no post-transform); (int(x*grid), int(y*grid)) -> i*grid + j.  Returns the number of indices (4^order).
+ */
+int64_t oracle_hilbert2d_flat(int grid, int64_t *out) {
+    int order = (int)log2((double)grid);
+    pts_t p;
+    memset(&p, 0, sizeof(p));
+    hilbert_rec(&p, 0, 0, 1.0, 0, 0, 1.0, order);
+    for (int64_t t = 0; t < p.n; t++)
+        out[t] = (int64_t)(p.x[t] * grid) * grid + (int64_t)(p.y[t] * grid);
+    int64_t n = p.n;
+    pts_free(&p);
+    return n;
 }

@@ -116,6 +116,112 @@ def tokenize(x, sd, cfg, prefix="patch_embed."):
     return t @ sd[prefix + "proj.weight"].t() + sd[prefix + "proj.bias"]
 
 
+def hierarchical_tokens(x, sd, img_size, patch_size_list, curve, prefix=""):
+    """HierarchicalHilbertEmbedding / HierarchicalMortonEmbedding.forward
+    (src/tokenizers/multiscale/multi_hilbert.py:31-40): level i = SFCEmbedding1D(pre_patch 2**i,
+    group patch_size_list[i]); coarser levels are linearly resampled to the first level's length,
+    concatenated on the feature axis and fused by a Linear.  `sd` keys: levels.{i}.sfc_indices,
+    levels.{i}.proj.{weight,bias}, fusion.{weight,bias}."""
+    outs = []
+    for i, g in enumerate(patch_size_list):
+        p = 2 ** i
+        t = tokens_sfc(x, sd[f"{prefix}levels.{i}.sfc_indices"], p, g)
+        outs.append(t @ sd[f"{prefix}levels.{i}.proj.weight"].t() + sd[f"{prefix}levels.{i}.proj.bias"])
+    n_tokens = outs[0].shape[1]
+    for i in range(1, len(outs)):
+        outs[i] = torch.nn.functional.interpolate(outs[i].transpose(1, 2), size=n_tokens, mode="linear",
+                                                  align_corners=False).transpose(1, 2)
+    cat = torch.cat(outs, dim=-1)
+    return cat @ sd[prefix + "fusion.weight"].t() + sd[prefix + "fusion.bias"]
+
+
+def hierarchical_state(img_size, in_channels, patch_size_list, embed_dim, curve):
+    """Formula-valued state of a hierarchical tokenizer (curve tables from the C oracle)."""
+    from . import formula
+    sd = {}
+    for i, g in enumerate(patch_size_list):
+        p = 2 ** i
+        grid = img_size // p
+        sd[f"levels.{i}.sfc_indices"] = torch.from_numpy(_curves.flat_table(curve, grid))
+        sd[f"levels.{i}.proj.weight"] = formula.param_value(f"levels.{i}.proj.weight", (embed_dim, in_channels * p * p * g))
+        sd[f"levels.{i}.proj.bias"] = formula.param_value(f"levels.{i}.proj.bias", (embed_dim,))
+    d = embed_dim * len(patch_size_list)
+    sd["fusion.weight"] = formula.param_value("fusion.weight", (d, d))
+    sd["fusion.bias"] = formula.param_value("fusion.bias", (d,))
+    return sd
+
+
+def _case_table(curve, grid, seed=None):
+    if curve == "randperm":       # RandomEmbedding.forward draws it per call (random_embedding.py:33)
+        torch.manual_seed(seed)
+        return torch.randperm(grid * grid)
+    return torch.from_numpy(_curves.flat_table(curve, grid))
+
+
+def tokenizer_case_state(args, kind):
+    """Formula-valued state_dict of one oracle.cases.TOKENIZER_CASES entry, with the reference's key names."""
+    from . import formula
+    img = args[0]
+    sd = {}
+    if kind[0] == "grouped":
+        _, curve, p, g, buf = kind
+        dim = args[-1]
+        if buf is not None:
+            flat = _case_table(curve, img // p)
+            if buf.endswith(":rc"):           # the _1D classes register (row, col) pairs
+                sd[buf[:-3]] = torch.stack([flat // (img // p), flat % (img // p)], dim=1)
+            else:
+                sd[buf] = flat
+        sd["proj.weight"] = formula.param_value("proj.weight", (dim, 3 * p * p * g))
+        sd["proj.bias"] = formula.param_value("proj.bias", (dim,))
+    elif kind[0] == "conv":
+        _, curve, p = kind
+        dim = args[-1]
+        sd["proj.weight"] = formula.param_value("proj.weight", (dim, 3, p, p))
+        sd["proj.bias"] = formula.param_value("proj.bias", (dim,))
+    else:
+        _, curve, plist, buf = kind
+        dim = args[-1]
+        for i, g in enumerate(plist):
+            p = 2 ** i
+            if buf is not None:
+                sd[f"levels.{i}.{buf}"] = _case_table(curve, img // p)
+            sd[f"levels.{i}.proj.weight"] = formula.param_value(f"levels.{i}.proj.weight", (dim, 3 * p * p * g))
+            sd[f"levels.{i}.proj.bias"] = formula.param_value(f"levels.{i}.proj.bias", (dim,))
+        d = dim * len(plist)
+        sd["fusion.weight"] = formula.param_value("fusion.weight", (d, d))
+        sd["fusion.bias"] = formula.param_value("fusion.bias", (d,))
+    return sd
+
+
+def tokenizer_case_forward(x, sd, args, kind, seed=None):
+    """Forward of one TOKENIZER_CASES entry.  grouped: onion_embedding1D.py:55-76, multi_onion.py:90-103,
+    multi_zigzag.py:85-97 (and the moore / peano twins of hilbert_embedding1D.py:30-44); conv:
+    _2D/zigzag_embedding.py:23-30, hilbert_embedding.py:81-92, random_embedding.py:23-37; hier: multi_*.py:30-40."""
+    img = args[0]
+    if kind[0] == "grouped":
+        _, curve, p, g, _ = kind
+        flat = _case_table(curve, img // p)
+        return tokens_sfc(x, flat, p, g) @ sd["proj.weight"].t() + sd["proj.bias"]
+    if kind[0] == "conv":
+        _, curve, p = kind
+        y = torch.nn.functional.conv2d(x, sd["proj.weight"], sd["proj.bias"], stride=p)   # [B, D, gh, gw]
+        y = y.flatten(2).transpose(1, 2)
+        if curve == "raster":
+            return y
+        return y[:, _case_table(curve, img // p, seed)]
+    _, curve, plist, _ = kind
+    outs = []
+    for i, g in enumerate(plist):
+        p = 2 ** i
+        t = tokens_sfc(x, _case_table(curve, img // p), p, g)
+        outs.append(t @ sd[f"levels.{i}.proj.weight"].t() + sd[f"levels.{i}.proj.bias"])
+    for i in range(1, len(outs)):
+        outs[i] = torch.nn.functional.interpolate(outs[i].transpose(1, 2), size=outs[0].shape[1], mode="linear",
+                                                  align_corners=False).transpose(1, 2)
+    return torch.cat(outs, dim=-1) @ sd["fusion.weight"].t() + sd["fusion.bias"]
+
+
 # ----------------------------------------------------------------------------
 # blocks
 # ----------------------------------------------------------------------------

@@ -128,6 +128,26 @@ int build(int curve, int n, std::vector<Cell> &kept) {
         for (int r = 0; r < n; r++)
             for (int c = 0; c < n; c++) full[size_t(r) * n + c] = {r, c};
         break;
+    case SFCVIT_CURVE_SPIRAL:
+        // Ring k: bottom row left->right, right column upwards, top row right->left, left column downwards;
+        // the next ring starts one cell up-right of where this one ended.
+        full.reserve(size_t(n) * n);
+        for (int k = 0; 2 * k < n; k++) {
+            const int lo = k, hi = n - 1 - k;
+            for (int c = lo; c <= hi; c++) full.push_back({hi, c});
+            for (int r = hi - 1; r >= lo; r--) full.push_back({r, hi});
+            if (hi > lo) {
+                for (int c = hi - 1; c >= lo; c--) full.push_back({lo, c});
+                for (int r = lo + 1; r <= hi - 1; r++) full.push_back({r, lo});
+            }
+        }
+        break;
+    case SFCVIT_CURVE_HILBERT_T: {
+        if (n & (n - 1)) return sfcvit::fail(SFCVIT_EINVAL, "transposed Hilbert table: n=%d must be a power of two", n);
+        gen_hilbert(order_for(n, 2), full);
+        for (Cell &c : full) std::swap(c.i, c.j);
+        break;
+    }
     default:
         return sfcvit::fail(SFCVIT_EINVAL, "curve table: unknown curve id %d", curve);
     }

@@ -24,7 +24,7 @@ using namespace gemm_core;
 struct Geo {
     const void *x;
     const int32_t *pix;
-    int B, C, HW, N, P, M, K;   // M = B*N token rows, K = C*P features
+    int B, C, HW, N, P, M, K, Kp;   // M = B*N token rows, K = C*P features, Kp = K rounded up to 8 (zero padded)
 };
 
 // 8 consecutive channel-major features f..f+7 of token row m, as bf16x8 bits.
@@ -65,7 +65,7 @@ __device__ __forceinline__ void load_tokens_kc(Stage &s, const Geo &g, int m0, i
     for (int i = 0; i < 4; i++) {
         const int v = tid + THREADS * i;
         const int m = m0 + (v >> 3), f = k0 + ((v & 7) << 3);
-        s.v[i] = (m < g.M && f < g.K) ? gather8<XBF16>(g, m, f) : u32x4{0u, 0u, 0u, 0u};
+        s.v[i] = (m < g.M && f < g.Kp) ? gather8<XBF16>(g, m, f) : u32x4{0u, 0u, 0u, 0u};
     }
 }
 
@@ -76,19 +76,19 @@ __device__ __forceinline__ void load_tokens_st(Stage &s, const Geo &g, int f0, i
     for (int i = 0; i < 4; i++) {
         const int v = tid + THREADS * i;
         const int m = m0 + (v >> 4), f = f0 + ((v & 15) << 3);
-        s.v[i] = (m < mend && f < g.K) ? gather8<XBF16>(g, m, f) : u32x4{0u, 0u, 0u, 0u};
+        s.v[i] = (m < mend && f < g.Kp) ? gather8<XBF16>(g, m, f) : u32x4{0u, 0u, 0u, 0u};
     }
 }
 
-// W'[d][c*P + kk] = W[d][kk*C + c]
+// W'[d][c*P + kk] = W[d][kk*C + c]; rows padded with zeros to Kp features
 __global__ __launch_bounds__(256) void permute_w_kernel(const uint16_t *__restrict__ w, uint16_t *__restrict__ wp, int D,
-                                                        int C, int P) {
+                                                        int C, int P, int Kp) {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     const int K = C * P;
-    if (i >= int64_t(D) * K) return;
-    const int d = int(i / K), f = int(i % K);
+    if (i >= int64_t(D) * Kp) return;
+    const int d = int(i / Kp), f = int(i % Kp);
     const int c = f / P, kk = f % P;
-    wp[i] = w[size_t(d) * K + kk * C + c];
+    wp[i] = f < K ? w[size_t(d) * K + kk * C + c] : uint16_t(0);
 }
 
 // y[m, d] = sum_f' tokens'[m, f'] W'[d, f'] + bias[d]
@@ -102,12 +102,12 @@ __global__ __launch_bounds__(THREADS, 2) void pe_fwd_kernel(const Geo g, const u
     const int tiles_n = (D + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const int nk = (g.K + BK - 1) / BK;
+    const int nk = (g.Kp + BK - 1) / BK;
     f32x4 acc[4][4];
     zero_acc(acc);
     Stage sa, sb;
     load_tokens_kc<XBF16>(sa, g, m0, 0, tid);
-    load_tile<false>(sb, wp, g.K, n0, D, 0, g.K, tid);
+    load_tile<false>(sb, wp, g.Kp, n0, D, 0, g.Kp, tid);
     store_tile<false>(sa, smem, tid);
     store_tile<false>(sb, smem + TILE_BYTES, tid);
     __syncthreads();
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(THREADS, 2) void pe_fwd_kernel(const Geo g, const u
         const bool more = kt + 1 < nk;
         if (more) {
             load_tokens_kc<XBF16>(sa, g, m0, (kt + 1) * BK, tid);
-            load_tile<false>(sb, wp, g.K, n0, D, (kt + 1) * BK, g.K, tid);
+            load_tile<false>(sb, wp, g.Kp, n0, D, (kt + 1) * BK, g.Kp, tid);
         }
         mma_tile<false, false>(acc, ia, ia + TILE_BYTES, wm, wn, lane);
         if (more) {
@@ -181,19 +181,19 @@ __global__ __launch_bounds__(THREADS, 2) void pe_bwd_kernel(const Geo g, const u
         __syncthreads();
     }
     mfma_fence();
-    store_partial(acc, slabs + size_t(blockIdx.z) * D * g.K, D, g.K, d0, f0, wm, wn, lane);
+    store_partial(acc, slabs + size_t(blockIdx.z) * D * g.Kp, D, g.Kp, d0, f0, wm, wn, lane);
 }
 
 // dW[d][kk*C + c] = sum_z slab[z][d][c*P + kk]
 __global__ __launch_bounds__(256) void pe_bwd_reduce(const float *__restrict__ slabs, int splits, float *__restrict__ dw,
-                                                     int D, int C, int P) {
+                                                     int D, int C, int P, int Kp) {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     const int K = C * P;
     if (i >= int64_t(D) * K) return;
     const int d = int(i / K), f = int(i % K);
     const int c = f / P, kk = f % P;
     float s = 0.f;
-    for (int z = 0; z < splits; z++) s += slabs[(size_t(z) * D + d) * K + f];
+    for (int z = 0; z < splits; z++) s += slabs[(size_t(z) * D + d) * Kp + f];
     dw[size_t(d) * K + kk * C + c] = s;
 }
 
@@ -211,7 +211,6 @@ int check_args(const sfcvit_patch_embed_args *a, const char *what) {
     if (a->B <= 0 || a->C <= 0 || a->HW <= 0 || a->N <= 0 || a->P <= 0 || a->D <= 0)
         return fail(SFCVIT_EINVAL, "%s: non-positive dimension", what);
     if (int64_t(a->N) * a->P != a->HW) return fail(SFCVIT_EINVAL, "%s: N*P=%lld must equal H*W=%d", what, (long long)a->N * a->P, a->HW);
-    if ((int64_t(a->C) * a->P) % 8 != 0) return fail(SFCVIT_EINVAL, "%s: C*P=%d must be a multiple of 8", what, a->C * a->P);
     if (a->D % 8 != 0) return fail(SFCVIT_EINVAL, "%s: D=%d must be a multiple of 8", what, a->D);
     if (int64_t(a->B) * a->N > 0x7fffffff / 2) return fail(SFCVIT_EINVAL, "%s: B*N too large", what);
     if (!aligned16(a->x) || !aligned16(a->pix) || !aligned16(a->y)) return fail(SFCVIT_EINVAL, "%s: alignment", what);
@@ -219,7 +218,7 @@ int check_args(const sfcvit_patch_embed_args *a, const char *what) {
 }
 
 Geo make_geo(const sfcvit_patch_embed_args *a) {
-    return Geo{a->x, a->pix, a->B, a->C, a->HW, a->N, a->P, a->B * a->N, a->C * a->P};
+    return Geo{a->x, a->pix, a->B, a->C, a->HW, a->N, a->P, a->B * a->N, a->C * a->P, (a->C * a->P + 7) / 8 * 8};
 }
 
 }  // namespace
@@ -229,9 +228,11 @@ using namespace sfcvit;
 
 extern "C" int64_t sfcvit_patch_embed_workspace(int B, int C, int N, int P, int D, int bwd) {
     if (B <= 0 || C <= 0 || N <= 0 || P <= 0 || D <= 0) return 0;
-    const int64_t K = int64_t(C) * P;
+    const int64_t K = (int64_t(C) * P + 7) / 8 * 8;
     if (!bwd) return ((int64_t(D) * K * 2 + 15) / 16) * 16;
-    return int64_t(bwd_splits(B * N, D, int(K))) * D * K * int64_t(sizeof(float));
+    const int64_t slabs = int64_t(bwd_splits(B * N, D, int(K))) * D * K * int64_t(sizeof(float));
+    const int64_t bias_ws = sfcvit_colsum_workspace(B * N, D);   // dbias reuses the buffer after the slabs are reduced
+    return slabs > bias_ws ? slabs : bias_ws;
 }
 
 extern "C" int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *stream) {
@@ -243,9 +244,9 @@ extern "C" int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *st
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Geo g = make_geo(a);
     uint16_t *wp = static_cast<uint16_t *>(a->workspace);
-    const int64_t nw = int64_t(a->D) * g.K;
+    const int64_t nw = int64_t(a->D) * g.Kp;
     hipLaunchKernelGGL(permute_w_kernel, dim3(unsigned((nw + 255) / 256)), dim3(256), 0, s,
-                       static_cast<const uint16_t *>(a->w), wp, a->D, a->C, a->P);
+                       static_cast<const uint16_t *>(a->w), wp, a->D, a->C, a->P, g.Kp);
     if (int rc = check_launch("patch_embed_fwd permute")) return rc;
     dim3 grid(((a->D + BN - 1) / BN) * ((g.M + BM - 1) / BM)), block(THREADS);
     const size_t lds = 4 * TILE_BYTES;
@@ -266,12 +267,12 @@ extern "C" int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *st
         return fail(SFCVIT_EINVAL, "patch_embed_bwd: workspace of %lld bytes needed", (long long)need);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Geo g = make_geo(a);
-    const int splits = bwd_splits(g.M, a->D, g.K);
+    const int splits = bwd_splits(g.M, a->D, g.Kp);
     const int ktiles = (g.M + BK - 1) / BK;
     const int m_per_split = ((ktiles + splits - 1) / splits) * BK;
     const int zs = (g.M + m_per_split - 1) / m_per_split;
     float *slabs = static_cast<float *>(a->workspace);
-    dim3 grid((g.K + BN - 1) / BN, (a->D + BM - 1) / BM, zs), block(THREADS);
+    dim3 grid((g.Kp + BN - 1) / BN, (a->D + BM - 1) / BM, zs), block(THREADS);
     const size_t lds = 4 * TILE_BYTES;
     if (a->x_is_bf16)
         hipLaunchKernelGGL(pe_bwd_kernel<true>, grid, block, lds, s, g, static_cast<const uint16_t *>(a->y), slabs, a->D, m_per_split);
@@ -280,8 +281,9 @@ extern "C" int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *st
     if (int rc = check_launch("patch_embed_bwd")) return rc;
     const int64_t nw = int64_t(a->D) * g.K;
     hipLaunchKernelGGL(pe_bwd_reduce, dim3(unsigned((nw + 255) / 256)), dim3(256), 0, s, slabs, zs,
-                       static_cast<float *>(a->dw), a->D, a->C, a->P);
+                       static_cast<float *>(a->dw), a->D, a->C, a->P, g.Kp);
     if (int rc = check_launch("patch_embed_bwd reduce")) return rc;
-    if (a->dbias) return sfcvit_colsum(a->y, g.M, a->D, a->D, static_cast<float *>(a->dbias), stream);
+    if (a->dbias)
+        return sfcvit_colsum(a->y, g.M, a->D, a->D, static_cast<float *>(a->dbias), a->workspace, a->workspace_bytes, stream);
     return SFCVIT_OK;
 }

@@ -237,8 +237,18 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(const uint16_t *__restr
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; r++) t += red[r][threadIdx.x];
-        atomicAdd(out + c, t);
+        out[size_t(blockIdx.y) * N + c] = t;          // partial[row block][column]
     }
+}
+
+// out[c] = sum over row blocks, in row-block order (no float atomics: the sum is reproducible)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ part, int nparts, int N,
+                                                            float *__restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float t = 0.f;
+    for (int y = 0; y < nparts; y++) t += part[size_t(y) * N + c];
+    out[c] = t;
 }
 
 // ---------------------------------------------------------------------------
@@ -416,8 +426,16 @@ __global__ __launch_bounds__(THREADS) void sumsq_kernel(const void *__restrict__
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; w++) t += red[w];
-        atomicAdd(out, t);
+        out[blockIdx.x] = t;                           // partial[block]
     }
+}
+
+// *out += sum of the block partials in a fixed order (lane-strided, then the wave butterfly)
+__global__ __launch_bounds__(64) void sumsq_reduce_kernel(const float *__restrict__ part, int nparts, float *__restrict__ out) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 64) t += part[i];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) *out += t;
 }
 
 // 8 elements per thread-iteration: bf16 param / grad as one 16-byte vector, fp32 master / m / v
@@ -546,21 +564,40 @@ extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *
     return sfcvit_layernorm_bwd_drop(dy, x, mean, rstd, gamma, dx_add, dx, nullptr, 0.f, 0u, dgamma, dbeta, nullptr, M, D, ws, stream);
 }
 
-extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *stream) {
+namespace {
+void colsum_plan(int M, int N, int &col_blocks, int &row_blocks, int &rpb) {
+    col_blocks = (N + 255) / 256;
+    row_blocks = 2048 / col_blocks;
+    if (row_blocks < 1) row_blocks = 1;
+    rpb = (M + row_blocks - 1) / row_blocks;
+    rpb = ((rpb + 7) / 8) * 8;
+    row_blocks = (M + rpb - 1) / rpb;
+}
+}  // namespace
+
+extern "C" int64_t sfcvit_colsum_workspace(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    int cb, rb, rpb;
+    colsum_plan(M, N, cb, rb, rpb);
+    return int64_t(rb) * N * int64_t(sizeof(float));
+}
+
+extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *workspace, int64_t workspace_bytes,
+                             void *stream) {
     if (!x || !out) return fail(SFCVIT_EINVAL, "colsum: null pointer");
     if (M <= 0 || N <= 0 || N % 8 || ld % 8 || ld < N) return fail(SFCVIT_EINVAL, "colsum: M=%d N=%d ld=%d (N, ld %% 8 == 0)", M, N, ld);
     if (!aligned16(x)) return fail(SFCVIT_EINVAL, "colsum: alignment");
+    const int64_t need = sfcvit_colsum_workspace(M, N);
+    if (!workspace || workspace_bytes < need) return fail(SFCVIT_EINVAL, "colsum: workspace of %lld bytes needed", (long long)need);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(out, 0, size_t(N) * sizeof(float), s) != hipSuccess) return check_launch("colsum memset");
-    const int col_blocks = (N + 255) / 256;
-    int row_blocks = 2048 / col_blocks;
-    if (row_blocks < 1) row_blocks = 1;
-    int rpb = (M + row_blocks - 1) / row_blocks;
-    rpb = ((rpb + 7) / 8) * 8;
-    row_blocks = (M + rpb - 1) / rpb;
+    int col_blocks, row_blocks, rpb;
+    colsum_plan(M, N, col_blocks, row_blocks, rpb);
+    float *part = static_cast<float *>(workspace);
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(THREADS), 0, s,
-                       static_cast<const uint16_t *>(x), M, N, ld, rpb, out);
-    return check_launch("colsum");
+                       static_cast<const uint16_t *>(x), M, N, ld, rpb, part);
+    if (int rc = check_launch("colsum")) return rc;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(col_blocks), dim3(256), 0, s, part, row_blocks, N, out);
+    return check_launch("colsum reduce");
 }
 
 extern "C" int sfcvit_transpose(const void *src, int R, int C, int lds, void *dst, int ldd, void *stream) {
@@ -627,14 +664,19 @@ extern "C" int sfcvit_soft_ce(const void *logits, const float *targets, float *l
     return check_launch("soft_ce");
 }
 
-extern "C" int sfcvit_sumsq_accum(const void *g, int64_t n, int is_f32, float *out, void *stream) {
-    if (!g || !out || n <= 0) return fail(SFCVIT_EINVAL, "sumsq: bad argument");
+extern "C" int sfcvit_sumsq_accum(const void *g, int64_t n, int is_f32, float *out, void *workspace, void *stream) {
+    if (!g || !out || !workspace || n <= 0) return fail(SFCVIT_EINVAL, "sumsq: bad argument");
     if (!aligned16(g)) return fail(SFCVIT_EINVAL, "sumsq: alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = grid_for((n + 7) / 8);
-    if (is_f32) hipLaunchKernelGGL(sumsq_kernel<true>, dim3(grid), dim3(THREADS), 0, s, g, n, out);
-    else hipLaunchKernelGGL(sumsq_kernel<false>, dim3(grid), dim3(THREADS), 0, s, g, n, out);
-    return check_launch("sumsq");
+    int grid = grid_for((n + 7) / 8);
+    const int max_parts = SFCVIT_SUMSQ_WORKSPACE_BYTES / int(sizeof(float));
+    if (grid > max_parts) grid = max_parts;
+    float *part = static_cast<float *>(workspace);
+    if (is_f32) hipLaunchKernelGGL(sumsq_kernel<true>, dim3(grid), dim3(THREADS), 0, s, g, n, part);
+    else hipLaunchKernelGGL(sumsq_kernel<false>, dim3(grid), dim3(THREADS), 0, s, g, n, part);
+    if (int rc = check_launch("sumsq")) return rc;
+    hipLaunchKernelGGL(sumsq_reduce_kernel, dim3(1), dim3(64), 0, s, part, grid, out);
+    return check_launch("sumsq reduce");
 }
 
 extern "C" int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream) {

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Entry script with the structure of the reference's main.py (seeds, tokenizer menu, model, AdamW +
+warm-up cosine schedule, MixUp/CutMix epochs, evaluate, checkpoint on best accuracy) running on the
+MI355X kernels.  The reference hard-codes everything and needs torchvision + a CIFAR-10 download; here
+the same defaults are arguments and `--synthetic` (default when torchvision is missing) feeds random
+CIFAR-shaped batches so that the script runs on an air-gapped GPU box.
+
+    python main.py --epochs 2 --synthetic                       # reference default model on 32x32
+    python main.py --tokenizer hilbert --img-size 224 --patch-size 256 --embed-dim 768 --depth 12 \\
+                   --heads 12 --mlp-dim 3072 --classes 1000 --batch-size 256 --synthetic
+    torchrun --nproc-per-node 8 main.py ...                     # data parallel (one process per GPU)
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from sfcvit.models.vit import VisionTransformer1D                                  # noqa: E402
+import sfcvit.tokenizers as T                                                       # noqa: E402
+from sfcvit.training import FusedAdamW, GradReducer, SoftTargetCrossEntropy, WarmupCosine   # noqa: E402
+from sfcvit.training.loops import evaluate, train_with_mixup_or_cutmix             # noqa: E402
+
+
+class SyntheticLoader:
+    """CIFAR-shaped random batches, regenerated deterministically every epoch."""
+
+    def __init__(self, n, batch, img, classes, seed, device):
+        self.n, self.batch, self.img, self.classes, self.seed, self.device = n, batch, img, classes, seed, device
+        self.dataset = range(n)
+
+    def __len__(self):
+        return self.n // self.batch
+
+    def __iter__(self):
+        g = torch.Generator(device=self.device).manual_seed(self.seed)
+        for _ in range(len(self)):
+            yield (torch.randn(self.batch, 3, self.img, self.img, device=self.device, generator=g),
+                   torch.randint(0, self.classes, (self.batch,), device=self.device, generator=g))
+
+
+def build_tokenizer(a):
+    one_d = {"raster": T.RasterScan1DEmbedding, "hilbert": T.HilbertEmbedding1D, "peano": T.PeanoEmbedding1D,
+             "moore": T.MooreEmbedding1D, "onion": T.OnionEmbedding1D, "morton": T.MortonEmbedding1D,
+             "zigzag": T.ZigzagEmbedding, "hilbert2d": T.HilbertEmbedding}           # main.py:232-240 (+ _2D/hilbert)
+    hier = {"hier_raster": T.HierarchicalRasterScanEmbedding, "hier_hilbert": T.HierarchicalHilbertEmbedding,
+            "hier_peano": T.HierarchicalPeanoEmbedding, "hier_moore": T.HierarchicalMooreEmbedding,
+            "hier_onion": T.HierarchicalOnionEmbedding, "hier_morton": T.HierarchicalMortonEmbedding}   # main.py:242-250
+    if a.tokenizer in one_d:
+        return one_d[a.tokenizer](a.img_size, a.patch_size, 3, a.embed_dim)
+    if a.tokenizer not in hier:
+        raise SystemExit(f"--tokenizer must be one of {sorted(one_d) + sorted(hier)}")
+    return hier[a.tokenizer](a.img_size, 3, a.levels, a.embed_dim)          # main.py:269-274: ([16, 4, 1], 256)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tokenizer", default="hier_morton")       # the reference's active menu entry (main.py:232-240)
+    ap.add_argument("--img-size", type=int, default=32)
+    ap.add_argument("--patch-size", type=int, default=256)
+    ap.add_argument("--levels", type=int, nargs="+", default=[16, 4, 1])
+    ap.add_argument("--embed-dim", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=8)             # main.py:276-282
+    ap.add_argument("--heads", type=int, default=12, help="head dim must be 64 for the HIP attention kernels "
+                    "(the reference's 768/4 = 192 is not supported yet)")
+    ap.add_argument("--mlp-dim", type=int, default=512)
+    ap.add_argument("--classes", type=int, default=10)
+    ap.add_argument("--batch-size", type=int, default=512)      # main.py:228
+    ap.add_argument("--epochs", type=int, default=300)          # main.py:306
+    ap.add_argument("--warmup-epochs", type=int, default=10)
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--weight-decay", type=float, default=5e-5)
+    ap.add_argument("--train-size", type=int, default=50000)
+    ap.add_argument("--test-size", type=int, default=10000)
+    ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--checkpoint-dir", default="./vit_checkpoints")
+    ap.add_argument("--resume", default=None)
+    a = ap.parse_args()
+
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    seed = 42                                                   # main.py:151-154
+    torch.manual_seed(seed)
+    np.random.seed(seed + rank)
+
+    try:
+        import torchvision  # noqa: F401
+        have_tv = True
+    except ImportError:
+        have_tv = False
+    if not a.synthetic and not have_tv:
+        print("torchvision is not installed: using --synthetic data")
+        a.synthetic = True
+    if not a.synthetic:
+        raise SystemExit("dataset loading is the reference's own (torchvision CIFAR-10, main.py:169-230); "
+                         "wire your DataLoader in here or pass --synthetic")
+    per_rank = a.batch_size // world
+    train_loader = SyntheticLoader(a.train_size // world, per_rank, a.img_size, a.classes, seed + 1 + rank, device)
+    test_loader = SyntheticLoader(a.test_size // world, per_rank, a.img_size, a.classes, seed + 1001 + rank, device)
+
+    patch_embed = build_tokenizer(a)
+    model = VisionTransformer1D(patch_embed=patch_embed, depth=a.depth, n_heads=a.heads, mlp_dim=a.mlp_dim,
+                                num_classes=a.classes).to(device, dtype=torch.bfloat16)   # main.py:157: bf16 parameters
+    train_criterion, test_criterion = SoftTargetCrossEntropy(), nn.CrossEntropyLoss()
+    optimizer = FusedAdamW(model.parameters(), lr=a.lr, weight_decay=a.weight_decay, max_grad_norm=1.0)
+    reducer = GradReducer(optimizer) if world > 1 else None
+    scheduler = WarmupCosine(optimizer, a.warmup_epochs * len(train_loader), a.epochs * len(train_loader))
+    start_epoch, best = 0, 0.0
+    if a.resume:
+        ck = torch.load(a.resume, map_location=device, weights_only=True)
+        model.load_state_dict(ck["model_state_dict"])
+        if ck.get("optimizer_state_dict"):
+            optimizer.load_state_dict(ck["optimizer_state_dict"])              # fp32 master weights + Adam moments
+        start_epoch, best = ck["epoch"] + 1, ck.get("test_acc", 0.0)
+        scheduler.n = ck.get("scheduler_state_dict", {}).get("n", start_epoch * len(train_loader))
+        optimizer.lr = scheduler.lr_at(scheduler.n)
+    os.makedirs(a.checkpoint_dir, exist_ok=True)
+    ckpt = os.path.join(a.checkpoint_dir, f"checkpoint_{a.tokenizer}.pt")
+
+    for epoch in range(start_epoch, a.epochs):
+        tr_loss, tr_acc = train_with_mixup_or_cutmix(model, train_loader, train_criterion, optimizer, scheduler,
+                                                     device, reducer=reducer)
+        te_loss, te_acc = evaluate(model, test_loader, test_criterion, device)
+        if rank == 0:
+            print(f"Epoch {epoch + 1}/{a.epochs} | Train Loss: {tr_loss:.4f}, Train Acc: {tr_acc:.4f} | "
+                  f"Test Loss: {te_loss:.4f}, Test Acc: {te_acc:.4f}")            # main.py:331-335
+            if te_acc > best or epoch == start_epoch:
+                best = te_acc
+                torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
+                            "optimizer_state_dict": optimizer.state_dict() if optimizer.master is not None else {},
+                            "scheduler_state_dict": {"n": scheduler.n}, "train_loss": tr_loss, "train_acc": tr_acc,
+                            "test_loss": te_loss, "test_acc": te_acc}, ckpt)      # main.py:345-354 keys
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

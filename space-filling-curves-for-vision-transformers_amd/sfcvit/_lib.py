@@ -62,7 +62,8 @@ SIGNATURES = {
     "sfcvit_gemm_workspace": (c_int64, [c_int, c_int, c_int]),
     "sfcvit_patch_embed_workspace": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sfcvit_transpose": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
-    "sfcvit_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sfcvit_colsum_workspace": (c_int64, [c_int, c_int]),
+    "sfcvit_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "sfcvit_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_float, c_void_p]),
     "sfcvit_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -80,7 +81,7 @@ SIGNATURES = {
     "sfcvit_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sfcvit_soft_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_float, c_void_p]),
-    "sfcvit_sumsq_accum": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "sfcvit_sumsq_accum": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "sfcvit_adamw_step": (c_int, [ctypes.POINTER(AdamWArgs), c_void_p]),
 }
 

@@ -191,7 +191,9 @@ def gemm_dx(dy, w, **kw):
 def colsum(x):
     _rows2d(x, _BF16, "colsum x")
     out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
-    check(lib.sfcvit_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(out), _stream()), "sfcvit_colsum")
+    nbytes = lib.sfcvit_colsum_workspace(x.shape[0], x.shape[1])
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    check(lib.sfcvit_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(out), _p(ws), nbytes, _stream()), "sfcvit_colsum")
     return out
 
 
@@ -373,7 +375,8 @@ def sumsq_accum(g, out):
     is_f32 = g.dtype == torch.float32
     if not is_f32:
         _need(g, _BF16, "sumsq g")
-    check(lib.sfcvit_sumsq_accum(_p(g), g.numel(), int(is_f32), _p(out), _stream()), "sfcvit_sumsq_accum")
+    ws = torch.empty(4096, device=g.device, dtype=torch.uint8)           # SFCVIT_SUMSQ_WORKSPACE_BYTES
+    check(lib.sfcvit_sumsq_accum(_p(g), g.numel(), int(is_f32), _p(out), _p(ws), _stream()), "sfcvit_sumsq_accum")
 
 
 def adamw_step(param, master, grad, m, v, sumsq, *, lr, beta1, beta2, eps, weight_decay, max_norm, step,

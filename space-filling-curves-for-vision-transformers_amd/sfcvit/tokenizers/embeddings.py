@@ -6,7 +6,10 @@ Same constructor signatures, attributes (`n_patches`, `input_dim`, `embed_dim`,
   MortonEmbedding1D      src/tokenizers/_1D/morton_embedding1D.py:9-44
   MooreEmbedding1D / PeanoEmbedding1D   src/tokenizers/_1D/{moore,peano}_embedding1D.py
   RasterScan1DEmbedding  src/tokenizers/_1D/zigzag_embedding1D.py:5-39
+  OnionEmbedding1D       src/tokenizers/_1D/onion_embedding1D.py:10-76 (spiral; no registered buffer)
   SFCEmbedding1D         src/tokenizers/multiscale/multi_hilbert.py:43-84
+  OnionGroupedEmbedding1D / RasterScan1DGroupedEmbedding   multiscale/multi_onion.py:46-103, multi_zigzag.py:55-97
+  ZigzagEmbedding / HilbertEmbedding / RandomEmbedding     src/tokenizers/_2D/*.py (Conv2d-weight tokenizers)
 The registered int64 buffer stays the source of truth (it is part of the
 state_dict); the kernel's per-token pixel table is derived from it on the host by
 sfcvit_pixel_table and cached on the device.
@@ -19,8 +22,8 @@ import torch.nn as nn
 
 from .. import functional as F
 from .._lib import lib, check
-from ..curves.space_filling_curves import (curve_table, curve_table_rc, hilbert_curve, moore_curve,
-                                           peano_curve, z_curve)
+from ..curves.space_filling_curves import (curve_table, curve_table_rc, hilbert_curve, hilbert_t_curve, moore_curve,
+                                           peano_curve, spiral_curve, z_curve)
 from .base_patch_embedding import BasePatchEmbedding
 
 
@@ -117,7 +120,21 @@ class RasterScan1DEmbedding(_FusedTokenizer):
         return None
 
 
+class OnionEmbedding1D(RasterScan1DEmbedding):
+    """Pixels in inward-spiral order from the bottom-left corner.  Like the reference class it registers no
+    index buffer (the walk is recomputed from the input size there), so state_dict holds `proj.*` only."""
+
+    def __init__(self, img_size, patch_size, in_channels, embed_dim):
+        super().__init__(img_size, patch_size, in_channels, embed_dim)
+        self._spiral = torch.from_numpy(curve_table(spiral_curve, img_size))
+
+    def _flat_table(self):
+        return self._spiral
+
+
 class SFCEmbedding1D(_FusedTokenizer):
+    _buffer = "sfc_indices"
+
     def __init__(self, img_size, pre_patch_size, group_patch_size, in_channels, embed_dim,
                  curve_fn=hilbert_curve):
         super().__init__()
@@ -134,8 +151,81 @@ class SFCEmbedding1D(_FusedTokenizer):
         self.n_patches = self.n_final_patches       # what VisionTransformer{,1D} reads (vit.py:354,422)
         self.pre_patch_dim = in_channels * pre_patch_size * pre_patch_size
         self.input_dim = self.pre_patch_dim * group_patch_size
-        self.register_buffer("sfc_indices", torch.from_numpy(curve_table(curve_fn, self.grid_size)).long())
+        if self._buffer is not None:
+            self.register_buffer(self._buffer, torch.from_numpy(curve_table(curve_fn, self.grid_size)).long())
         self._setup(img_size, pre_patch_size, group_patch_size, in_channels, embed_dim)
 
     def _flat_table(self):
-        return self.sfc_indices
+        return None if self._buffer is None else getattr(self, self._buffer)
+
+
+class OnionGroupedEmbedding1D(SFCEmbedding1D):
+    """multiscale/multi_onion.py:46-103 (named OnionEmbedding1D there; buffer `onion_indices`)."""
+    _buffer = "onion_indices"
+
+    def __init__(self, img_size, pre_patch_size, group_patch_size, in_channels, embed_dim):
+        super().__init__(img_size, pre_patch_size, group_patch_size, in_channels, embed_dim, spiral_curve)
+
+
+class RasterScan1DGroupedEmbedding(SFCEmbedding1D):
+    """multiscale/multi_zigzag.py:55-97: pre-patches in raster order, no buffer."""
+    _buffer = None
+
+    def __init__(self, img_size, pre_patch_size, group_patch_size, in_channels, embed_dim):
+        super().__init__(img_size, pre_patch_size, group_patch_size, in_channels, embed_dim, None)
+
+
+class _Conv2dTokenizer(_FusedTokenizer):
+    """p x p patches projected by an nn.Conv2d(kernel = stride = p) weight [D, C, p, p]; the fused kernel wants
+    the features of a patch ordered (p1, p2, c), so the weight is viewed through a permute (1.2 MB at ViT-B,
+    differentiable) instead of running a convolution."""
+
+    def __init__(self, img_size, patch_size, in_channels, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_channels, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.img_size = img_size
+        self.embed_dim = embed_dim
+        self.grid_size = img_size // patch_size
+        self.n_patches = self.grid_size ** 2
+        self._geom = (img_size, patch_size, 1)
+        self._pix = None
+        self._pix_key = None
+
+    def _flat_table(self):
+        return None
+
+    def forward(self, x):
+        img = self._geom[0]
+        if x.dim() != 4 or x.shape[2] != img or x.shape[3] != img:
+            raise ValueError(f"expected [B, C, {img}, {img}] input, got {tuple(x.shape)}")
+        w = self.proj.weight
+        w2 = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+        return F.patch_embed(x, self._pix_table(x.device), w2, self.proj.bias)
+
+
+class ZigzagEmbedding(_Conv2dTokenizer):
+    """src/tokenizers/_2D/zigzag_embedding.py:5-30: the standard ViT patch embedding, raster token order."""
+
+
+class HilbertEmbedding(_Conv2dTokenizer):
+    """src/tokenizers/_2D/hilbert_embedding.py:9-92: ViT patches visited along a Hilbert curve (power-of-two
+    grids; `hilbert_indices` is a plain attribute there, not a buffer, and stays one here)."""
+
+    def __init__(self, img_size, patch_size, in_channels, embed_dim):
+        super().__init__(img_size, patch_size, in_channels, embed_dim)
+        self.hilbert_indices = torch.from_numpy(curve_table(hilbert_t_curve, self.grid_size)).long()
+
+    def _flat_table(self):
+        return self.hilbert_indices
+
+
+class RandomEmbedding(_Conv2dTokenizer):
+    """src/tokenizers/_2D/random_embedding.py:6-37: a fresh torch.randperm(N) of the patches on every call
+    (drawn from torch's CPU generator, as in the reference)."""
+
+    def forward(self, x):
+        self._perm = torch.randperm(self.n_patches)
+        return super().forward(x)
+
+    def _flat_table(self):
+        return self._perm

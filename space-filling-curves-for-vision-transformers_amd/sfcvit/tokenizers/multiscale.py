@@ -1,0 +1,84 @@
+"""Hierarchical (multi-scale) curve tokenizers: several SFCEmbedding1D levels, resampled to a common
+length, concatenated on the feature axis and fused by a Linear
+(reference: src/tokenizers/multiscale/multi_hilbert.py:9-40, multi_morton.py:9-40; what the reference's
+main.py:269-274 instantiates).  Every level and the fusion run on the HIP kernels; the resampling
+(identity-sized in the reference's own configuration) and the concatenation are plain torch plumbing."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from ..curves.space_filling_curves import hilbert_curve, moore_curve, peano_curve, z_curve
+from .embeddings import OnionGroupedEmbedding1D, RasterScan1DGroupedEmbedding, SFCEmbedding1D
+
+
+class _Hierarchical(nn.Module):
+    _default_curve = hilbert_curve
+
+    def __init__(self, img_size, in_channels, patch_size_list, embed_dim, curve_fn=None):
+        super().__init__()
+        curve_fn = curve_fn or type(self)._default_curve
+        self.levels = nn.ModuleList()
+        pre_patch_size, pre_patch_list = 1, []
+        for patch_size in patch_size_list:
+            self.levels.append(self._level(img_size, pre_patch_size, patch_size, in_channels, embed_dim, curve_fn))
+            pre_patch_list.append(pre_patch_size)
+            pre_patch_size *= 2
+        self.patch_list = [int(((img_size // pre) // np.sqrt(ps)) ** 2) for pre, ps in zip(pre_patch_list, patch_size_list)]
+        self.embed_dim = embed_dim * len(patch_size_list)
+        self.depth = len(patch_size_list)
+        self.n_patches = self.patch_list[0]
+        self.fusion = nn.Linear(self.embed_dim, self.embed_dim)
+
+    @staticmethod
+    def _level(img_size, pre_patch_size, patch_size, in_channels, embed_dim, curve_fn):
+        return SFCEmbedding1D(img_size, pre_patch_size, patch_size, in_channels, embed_dim, curve_fn)
+
+    def forward(self, x):
+        patches = [level(x) for level in self.levels]
+        n_tokens = self.patch_list[0]
+        for i in range(1, len(patches)):
+            if patches[i].shape[1] != n_tokens:
+                patches[i] = torch.nn.functional.interpolate(patches[i].transpose(1, 2), size=n_tokens, mode="linear",
+                                                             align_corners=False).transpose(1, 2)
+        return F.linear(torch.cat(patches, dim=-1), self.fusion.weight, self.fusion.bias)
+
+
+class HierarchicalHilbertEmbedding(_Hierarchical):
+    _default_curve = hilbert_curve
+
+
+class HierarchicalMortonEmbedding(_Hierarchical):
+    _default_curve = z_curve
+
+
+class HierarchicalMooreEmbedding(_Hierarchical):
+    """multiscale/multi_moore.py:9-40."""
+    _default_curve = moore_curve
+
+
+class HierarchicalPeanoEmbedding(_Hierarchical):
+    """multiscale/multi_peano.py:9-40."""
+    _default_curve = peano_curve
+
+
+class HierarchicalOnionEmbedding(_Hierarchical):
+    """multiscale/multi_onion.py:8-43 (levels carry `onion_indices`)."""
+
+    def __init__(self, img_size, in_channels, patch_size_list, embed_dim):
+        super().__init__(img_size, in_channels, patch_size_list, embed_dim)
+
+    @staticmethod
+    def _level(img_size, pre_patch_size, patch_size, in_channels, embed_dim, curve_fn):
+        return OnionGroupedEmbedding1D(img_size, pre_patch_size, patch_size, in_channels, embed_dim)
+
+
+class HierarchicalRasterScanEmbedding(_Hierarchical):
+    """multiscale/multi_zigzag.py:7-52 (levels have no index buffer)."""
+
+    def __init__(self, img_size, in_channels, patch_size_list, embed_dim):
+        super().__init__(img_size, in_channels, patch_size_list, embed_dim)
+
+    @staticmethod
+    def _level(img_size, pre_patch_size, patch_size, in_channels, embed_dim, curve_fn):
+        return RasterScan1DGroupedEmbedding(img_size, pre_patch_size, patch_size, in_channels, embed_dim)

@@ -31,8 +31,10 @@ class FlatGradBuffer:
     def _check(self, p):
         pass
 
-    def _build(self):
-        self.active = [p for p in self.params if p.grad is not None]
+    def _build(self, active=None):
+        """`active` = the parameters that receive gradients; by default those that have one now (after the first
+        backward), which leaves out parameters the forward never touches (mlp_mixer.token_mix*, vit.py:269-272)."""
+        self.active = [p for p in self.params if p.grad is not None] if active is None else list(active)
         if not self.active:
             raise RuntimeError("step() before any backward")
         dev, dtype = self.active[0].device, self.active[0].dtype
@@ -49,7 +51,8 @@ class FlatGradBuffer:
         for p, o in zip(self.active, self.offsets):
             k = p.numel()
             self.flat_param[o:o + k].copy_(p.detach().reshape(-1))
-            self.flat_grad[o:o + k].copy_(p.grad.reshape(-1))
+            if p.grad is not None:
+                self.flat_grad[o:o + k].copy_(p.grad.reshape(-1))
             p.data = self.flat_param[o:o + k].view(p.shape)
             p.grad = self.flat_grad[o:o + k].view(p.shape)
         self._built()
@@ -77,10 +80,20 @@ class FusedAdamW(FlatGradBuffer):
     def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-5, max_grad_norm=1.0,
                  grad_scale=1.0):
         super().__init__(params, grad_scale)
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        # one group, shaped like torch.optim's so that schedulers written against `param_groups[0]['lr']` work
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
         self.master = self.m = self.v = self._sumsq = None
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]["lr"] = value
 
     def _check(self, p):
         if p.dtype != torch.bfloat16 or not p.is_cuda:
@@ -112,11 +125,15 @@ class FusedAdamW(FlatGradBuffer):
         return self._sumsq.sqrt() * self.grad_scale
 
     def state_dict(self):
-        return {"step": self.step_count, "lr": self.lr, "master": self.master, "m": self.m, "v": self.v}
+        index = {id(p): i for i, p in enumerate(self.params)}
+        return {"step": self.step_count, "lr": self.lr, "master": self.master, "m": self.m, "v": self.v,
+                "active": [index[id(p)] for p in self.active]}
 
     def load_state_dict(self, sd):
         if self.flat_grad is None:
-            raise RuntimeError("run one step before load_state_dict (the flat layout is built then)")
+            self._build([self.params[i] for i in sd["active"]])
+        if self.master.numel() != sd["master"].numel():
+            raise ValueError("optimizer state does not fit these parameters")
         self.step_count, self.lr = sd["step"], sd["lr"]
         self.master.copy_(sd["master"])
         self.m.copy_(sd["m"])
@@ -146,3 +163,29 @@ class WarmupCosine:
     def step(self):
         self.n += 1
         self.opt.lr = self.lr_at(self.n)
+
+
+class WarmupCosineScheduler:
+    """src/training/scheduler.py:4-51: linear warm-up to base_lr, cosine decay to min_lr; step() sets the rate for
+    the step about to run, returns it, then advances.  Works on torch optimizers and on FusedAdamW."""
+
+    def __init__(self, optimizer, warmup_steps, total_steps, min_lr=1e-6, base_lr=None):
+        import math
+        self._math = math
+        self.optimizer = optimizer
+        self.warmup_steps = warmup_steps
+        self.total_steps = total_steps
+        self.min_lr = min_lr
+        self.base_lr = optimizer.param_groups[0]["lr"] if base_lr is None else base_lr
+        self.current_step = 0
+
+    def step(self):
+        if self.current_step < self.warmup_steps:
+            lr = self.base_lr * (self.current_step / max(1, self.warmup_steps))
+        else:
+            progress = (self.current_step - self.warmup_steps) / max(1, self.total_steps - self.warmup_steps)
+            lr = self.min_lr + 0.5 * (self.base_lr - self.min_lr) * (1 + self._math.cos(self._math.pi * min(1.0, progress)))
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+        self.current_step += 1
+        return lr

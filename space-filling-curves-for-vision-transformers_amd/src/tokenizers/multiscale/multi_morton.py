@@ -1,0 +1,2 @@
+from sfcvit.tokenizers.embeddings import SFCEmbedding1D  # noqa: F401
+from sfcvit.tokenizers.multiscale import HierarchicalMortonEmbedding  # noqa: F401

@@ -160,3 +160,112 @@ def test_training_mode_on_cpu_is_rejected_too():
     model = build_model(cfg).train()            # dropout 0.1 / 0.5 as in the reference: fused in the HIP kernels
     with pytest.raises(SfcvitError, match="no CPU fallback"):
         model(torch.zeros(batch, 3, 32, 32))
+
+
+def test_reference_import_paths_resolve_to_the_hip_modules():
+    """A script written against the reference's package layout (`from src.… import …`) runs unchanged with
+    space-filling-curves-for-vision-transformers_amd/ on sys.path."""
+    import importlib
+    import sfcvit.models.vit as vit
+    import sfcvit.tokenizers as tok
+    pairs = [("src.models.vit", "VisionTransformer1D", vit.VisionTransformer1D),
+             ("src.models.vit", "VisionTransformer", vit.VisionTransformer),
+             ("src.tokenizers._1D.hilbert_embedding1D", "HilbertEmbedding1D", tok.HilbertEmbedding1D),
+             ("src.tokenizers._1D.morton_embedding1D", "MortonEmbedding1D", tok.MortonEmbedding1D),
+             ("src.tokenizers._1D.zigzag_embedding1D", "RasterScan1DEmbedding", tok.RasterScan1DEmbedding),
+             ("src.tokenizers.multiscale.multi_hilbert", "HierarchicalHilbertEmbedding", tok.HierarchicalHilbertEmbedding),
+             ("src.tokenizers.multiscale.multi_hilbert", "SFCEmbedding1D", tok.SFCEmbedding1D),
+             ("src.tokenizers.multiscale.multi_morton", "HierarchicalMortonEmbedding", tok.HierarchicalMortonEmbedding)]
+    for mod, name, obj in pairs:
+        assert getattr(importlib.import_module(mod), name) is obj, (mod, name)
+    for mod, names in [("src.curves.space_filling_curves", ["hilbert_curve", "z_curve", "embed_and_prune_sfc"]),
+                       ("src.training.train", ["train_with_mixup_or_cutmix", "mixup_data", "cutmix_data", "rand_bbox",
+                                               "mixup_criterion", "evaluate"])]:
+        m = importlib.import_module(mod)
+        for n in names:
+            assert callable(getattr(m, n)), (mod, n)
+
+
+def test_reference_default_model_has_the_reference_parameter_count(golden_dir):
+    """main.py:269-282: HierarchicalMortonEmbedding(32, 3, [16, 4, 1], 256) + 8 layers."""
+    from sfcvit.models.vit import VisionTransformer1D
+    from sfcvit.tokenizers import HierarchicalMortonEmbedding
+    pe = HierarchicalMortonEmbedding(32, 3, [16, 4, 1], 256)
+    assert (pe.n_patches, pe.embed_dim) == (64, 768)
+    model = VisionTransformer1D(pe, depth=8, n_heads=4, mlp_dim=512, num_classes=10)
+    assert sum(p.numel() for p in model.parameters()) == 34_773_834
+    with open(os.path.join(golden_dir, "hierarchical.json")) as f:
+        gold = json.load(f)["hier_morton32"]
+    small = HierarchicalMortonEmbedding(32, 3, [16, 4, 1], 64)
+    assert {k: list(v.shape) for k, v in small.state_dict().items()} == gold["keys"]
+
+
+def test_mixup_cutmix_helpers_follow_the_reference_contract():
+    """src/training/train.py:9-87: lam ~ Beta(alpha, alpha); CutMix pastes one box from the permuted batch and
+    corrects lam to the pasted area."""
+    from sfcvit.training.loops import cutmix_data, mixup_data, rand_bbox
+    torch.manual_seed(0)
+    np.random.seed(0)
+    x = torch.randn(8, 3, 16, 16)
+    y = torch.arange(8)
+    mx, ya, yb, lam = mixup_data(x, y, alpha=1.0)
+    assert mx.shape == x.shape and 0.0 <= lam <= 1.0 and torch.equal(ya, y) and sorted(yb.tolist()) == list(range(8))
+    perm = yb
+    assert torch.allclose(mx, lam * x + (1 - lam) * x[perm], atol=1e-6)
+    x1, y1 = rand_bbox(16, 16, 0.75)[0:2]
+    cx, ya, yb, lam = cutmix_data(x.clone(), y, alpha=1.0)
+    changed = (cx != x).any(dim=1).any(dim=0)               # [H, W] mask of pasted pixels
+    assert abs((1.0 - changed.float().mean().item()) - lam) < 1e-6 or changed.sum() == 0
+
+
+def test_spiral_and_2d_hilbert_native_tables_match_reference_fixture(sfc, golden_dir):
+    from oracle.cases import SPIRAL_N, HILBERT_T_N
+    gold = np.load(os.path.join(golden_dir, "curves_extra.npz"))
+    for n in SPIRAL_N:
+        assert np.array_equal(sfc.curve_table(sfc.spiral_curve, n), gold[f"spiral_{n}"]), n
+    for n in HILBERT_T_N:
+        assert np.array_equal(sfc.curve_table(sfc.hilbert_t_curve, n), gold[f"hilbert_t_{n}"]), n
+    for n in (224, 384, 77):
+        assert np.array_equal(sfc.curve_table(sfc.spiral_curve, n), ocurves.flat_table("spiral", n)), n
+    with pytest.raises(Exception, match="power of two"):
+        sfc.curve_table(sfc.hilbert_t_curve, 14)
+
+
+def _tok_cases():
+    from oracle.cases import TOKENIZER_CASES
+    return sorted(TOKENIZER_CASES)
+
+
+@pytest.mark.parametrize("name", _tok_cases())
+def test_remaining_tokenizers_have_the_reference_surface(name, golden_dir):
+    """Same import path (through src.*), constructor, state_dict keys/shapes and n_patches / embed_dim attributes."""
+    import importlib
+    from oracle.cases import TOKENIZER_CASES
+    modname, clsname, args, kind, _ = TOKENIZER_CASES[name]
+    with open(os.path.join(golden_dir, "tokenizers.json")) as f:
+        gold = json.load(f)[name]
+    mod = getattr(importlib.import_module(modname), clsname)(*args)
+    assert {k: list(v.shape) for k, v in mod.state_dict().items()} == gold["keys"]
+    assert int(getattr(mod, "n_patches", getattr(mod, "n_final_patches", -1))) == gold["n_patches"] or gold["n_patches"] == -1
+    if hasattr(mod, "embed_dim"):
+        assert mod.embed_dim == gold["embed_dim"]
+    from oracle import vit_oracle
+    sd = vit_oracle.tokenizer_case_state(args, kind)
+    for k, v in mod.state_dict().items():
+        if not v.is_floating_point():
+            assert torch.equal(v, sd[k]), k                 # index buffers identical to the oracle's
+
+
+def test_warmup_cosine_scheduler_values():
+    """src/training/scheduler.py:33-51: lr(step) for warm-up 4, total 12, base 1e-3, floor 1e-6."""
+    import math
+    from src.training.scheduler import WarmupCosineScheduler
+
+    class Opt:
+        param_groups = [{"lr": 1e-3}, {"lr": 5.0}]
+    sched = WarmupCosineScheduler(Opt, warmup_steps=4, total_steps=12, min_lr=1e-6)
+    got = [sched.step() for _ in range(15)]
+    want = [1e-3 * s / 4 for s in range(4)] + \
+           [1e-6 + 0.5 * (1e-3 - 1e-6) * (1 + math.cos(math.pi * min(1.0, (s - 4) / 8))) for s in range(4, 15)]
+    assert got == pytest.approx(want, rel=1e-12)
+    assert Opt.param_groups[0]["lr"] == Opt.param_groups[1]["lr"] == got[-1] == pytest.approx(1e-6)

@@ -94,3 +94,47 @@ def test_model_against_reference_fixture(name, golden_dir):
         got = torch.stack([mine[i] for i in g["idx"]])
         assert torch.allclose(got, torch.tensor(g["val"]).double(), rtol=2e-3,
                               atol=2e-4 * g["l2"] / max(1.0, mine.numel() ** 0.5) + 1e-9), k
+
+
+@pytest.mark.parametrize("name", ["hier_morton32", "hier_hilbert32_resample"])
+def test_hierarchical_tokenizer_against_reference_fixture(name, golden_dir):
+    from oracle.cases import HIER_CASES
+    img, cin, plist, dim, curve, batch = HIER_CASES[name]
+    with open(os.path.join(golden_dir, "hierarchical.json")) as f:
+        gold = json.load(f)[name]
+    sd = vit_oracle.hierarchical_state(img, cin, plist, dim, curve)
+    assert {k: list(v.shape) for k, v in sd.items()} == gold["keys"]
+    y = vit_oracle.hierarchical_tokens(formula.image_batch(batch, cin, img, img), sd, img, plist, curve)
+    assert list(y.shape) == gold["shape"]
+    got = torch.stack([y.flatten()[i] for i in gold["idx"]]).double()
+    assert torch.allclose(got, torch.tensor(gold["val"], dtype=torch.float64), rtol=1e-4, atol=1e-5)
+    assert abs(float(y.double().norm()) - gold["l2"]) < 1e-4 * gold["l2"]
+
+
+def _tok_cases():
+    from oracle.cases import TOKENIZER_CASES
+    return sorted(TOKENIZER_CASES)
+
+
+@pytest.mark.parametrize("name", _tok_cases())
+def test_remaining_tokenizers_against_reference_fixture(name, golden_dir):
+    from oracle.cases import TOKENIZER_CASES, RANDPERM_SEED
+    _, _, args, kind, batch = TOKENIZER_CASES[name]
+    with open(os.path.join(golden_dir, "tokenizers.json")) as f:
+        gold = json.load(f)[name]
+    sd = vit_oracle.tokenizer_case_state(args, kind)
+    assert {k: list(v.shape) for k, v in sd.items()} == gold["keys"]
+    y = vit_oracle.tokenizer_case_forward(formula.image_batch(batch, 3, args[0], args[0]), sd, args, kind, RANDPERM_SEED)
+    assert list(y.shape) == gold["shape"]
+    got = torch.stack([y.flatten()[i] for i in gold["idx"]]).double()
+    assert torch.allclose(got, torch.tensor(gold["val"], dtype=torch.float64), rtol=1e-4, atol=1e-5)
+    assert abs(float(y.double().norm()) - gold["l2"]) < 1e-4 * gold["l2"]
+
+
+def test_spiral_and_2d_hilbert_tables_against_reference_fixture(golden_dir):
+    from oracle.cases import SPIRAL_N, HILBERT_T_N
+    gold = np.load(os.path.join(golden_dir, "curves_extra.npz"))
+    for n in SPIRAL_N:
+        assert np.array_equal(ocurves.flat_table("spiral", n), gold[f"spiral_{n}"]), n
+    for n in HILBERT_T_N:
+        assert np.array_equal(ocurves.flat_table("hilbert_t", n), gold[f"hilbert_t_{n}"]), n

@@ -42,7 +42,9 @@ def main():
     from src.tokenizers.multiscale.multi_hilbert import SFCEmbedding1D
     from src.models.vit import VisionTransformer, VisionTransformer1D
     from oracle import formula
-    from oracle.cases import MODEL_CASES, CURVE_SMALL_N, CURVE_SHA_N, CURVE_KINDS
+    from oracle.cases import MODEL_CASES, CURVE_SMALL_N, CURVE_SHA_N, CURVE_KINDS, HIER_CASES
+    from src.tokenizers.multiscale.multi_hilbert import HierarchicalHilbertEmbedding
+    from src.tokenizers.multiscale.multi_morton import HierarchicalMortonEmbedding
 
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -117,6 +119,50 @@ def main():
         with open(os.path.join(GOLD, f"model_{name}.json"), "w") as f:
             json.dump(out, f)
         print(name, "loss", out["loss"], "logits[0][:3]", out["logits"][0][:3])
+    # ---- hierarchical tokenizers ----------------------------------------------
+    hier = {}
+    for name, (img, cin, plist, dim, curve, batch) in HIER_CASES.items():
+        cls = HierarchicalMortonEmbedding if curve == "z" else HierarchicalHilbertEmbedding
+        mod = cls(img, cin, plist, dim)
+        mod.load_state_dict(formula.fill_state_dict(mod.state_dict()))
+        x = formula.image_batch(batch, cin, img, img)
+        y = mod(x).detach()
+        idx = sample_idx(y.numel(), 64)
+        yf = y.flatten()
+        hier[name] = {"shape": list(y.shape), "l2": float(y.double().norm()), "idx": idx,
+                      "val": [float(yf[i]) for i in idx], "n_patches": mod.n_patches, "embed_dim": mod.embed_dim,
+                      "keys": {k: list(v.shape) for k, v in mod.state_dict().items()}}
+        print(name, hier[name]["shape"], hier[name]["l2"])
+    with open(os.path.join(GOLD, "hierarchical.json"), "w") as f:
+        json.dump(hier, f)
+    # ---- remaining tokenizers ------------------------
+    import importlib
+    from oracle.cases import TOKENIZER_CASES, RANDPERM_SEED, SPIRAL_N, HILBERT_T_N
+    toks = {}
+    for name, (modname, clsname, args, kind, batch) in TOKENIZER_CASES.items():
+        mod = getattr(importlib.import_module(modname), clsname)(*args)
+        mod.load_state_dict(formula.fill_state_dict(mod.state_dict()))
+        x = formula.image_batch(batch, 3, args[0], args[0])
+        torch.manual_seed(RANDPERM_SEED)
+        y = mod(x).detach()
+        idx = sample_idx(y.numel(), 64)
+        yf = y.flatten()
+        toks[name] = {"shape": list(y.shape), "l2": float(y.double().norm()), "idx": idx,
+                      "val": [float(yf[i]) for i in idx], "n_patches": int(getattr(mod, "n_patches", getattr(mod, "n_final_patches", -1))),
+                      "embed_dim": int(getattr(mod, "embed_dim", y.shape[-1])),
+                      "keys": {k: list(v.shape) for k, v in mod.state_dict().items()}}
+        print(name, toks[name]["shape"], toks[name]["l2"])
+    with open(os.path.join(GOLD, "tokenizers.json"), "w") as f:
+        json.dump(toks, f)
+    from src.tokenizers._1D.onion_embedding1D import OnionEmbedding1D
+    from src.tokenizers._2D.hilbert_embedding import HilbertEmbedding
+    extra = {}
+    for n in SPIRAL_N:
+        r, c = OnionEmbedding1D(n, 1, 3, 4).onion_indices(n, n)
+        extra[f"spiral_{n}"] = (np.asarray(r) * n + np.asarray(c)).astype(np.int32)
+    for n in HILBERT_T_N:
+        extra[f"hilbert_t_{n}"] = HilbertEmbedding(n, 1, 3, 4).hilbert_indices.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(GOLD, "curves_extra.npz"), **extra)
     with open(os.path.join(GOLD, "state_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     return 0
