@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ w
 }  // namespace
 
 int gemm256_dispatch(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s);   // gemm256.hip
+int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s);                        // gemm8p.hip
 
 }  // namespace sfcvit
 
@@ -157,6 +158,11 @@ extern "C" int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream) {
     }
 
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a->force_generic == 0 || a->force_generic == 8 || a->force_generic == 9) {
+        const int p8 = gemm8p_dispatch(*a, splits, s);
+        if (p8 >= 0) return p8;
+        if (a->force_generic != 0) return fail(SFCVIT_EINVAL, "gemm: shape / options not eligible for the persistent 8-phase kernel");
+    }
     const int big = (a->force_generic == 1) ? -1 : gemm256_dispatch(*a, splits, k_per_split, s);
     if (big > 0) return big;
     dim3 grid(((a->N + BN - 1) / BN) * ((a->M + BM - 1) / BM) * splits), block(THREADS);

@@ -307,3 +307,63 @@ def test_gemm_row_slices_share_one_dropout_mask(ops):
     hi = ops.gemm(a[512:], w, row_offset=512, **kw)
     assert torch.equal(full, torch.cat([lo, hi]))
     assert torch.equal(full, ops.gemm(a, w, force_generic=1, **kw))
+
+
+# ---------------------------------------------------------------------------------------------------
+# persistent 8-phase kernel (gemm8p.hip): force_generic 8 = 256-row tiles, 9 = 224-row tiles
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,mode", [
+    (256, 256, 128, 8),          # one tile, two k-tiles
+    (512, 512, 256, 8),          # 4 tiles
+    (224, 256, 128, 9),          # one 224-row tile
+    (448, 768, 384, 9),
+    (256 * 37, 256 * 7, 128, 8),     # 259 tiles on 256 workgroups: the second round of the tile list, short k loop
+    (224 * 40, 256 * 7, 256, 9),     # 280 tiles
+    (256 * 12, 768, 768, 8),         # ViT-B k loop
+])
+def test_gemm_persistent_kernel_against_fp32_and_generic(ops, M, N, K, mode):
+    g = torch.Generator(device="cuda").manual_seed(21)
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) * 0.1)
+    bias = bf(torch.randn(N, device="cuda", generator=g))
+    c = ops.gemm(a, w, bias=bias, force_generic=mode)
+    close(c, a.float() @ w.float().t() + bias.float())
+    assert torch.equal(c, ops.gemm(a, w, bias=bias, force_generic=1))
+    assert torch.equal(ops.gemm(a, w, force_generic=mode), ops.gemm(a, w, force_generic=1))
+
+
+@pytest.mark.parametrize("mode,M", [(8, 1024), (9, 896)])
+def test_gemm_persistent_kernel_epilogues(ops, mode, M):
+    """Every epilogue variant the persistent kernel is built for gives bit-identical results to the generic kernel
+    (same fp32 accumulation order per k-tile is not guaranteed in general, so first compare against fp32 math)."""
+    N, K = 512, 256
+    g = torch.Generator(device="cuda").manual_seed(22)
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) * 0.1)
+    bias = bf(torch.randn(N, device="cuda", generator=g))
+    res = bf(torch.randn(M, N, device="cuda", generator=g))
+    aux = bf(torch.randn(M, N, device="cuda", generator=g))
+    variants = [dict(bias=bias, residual=res), dict(bias=bias, residual=res, dropout_p=0.1, dropout_seed=77),
+                dict(bias=bias, act=ops.ACT_RELU), dict(bias=bias, act=ops.ACT_RELU, dropout_p=0.1, dropout_seed=5),
+                dict(aux_in=aux, dact=ops.ACT_RELU, dact_scale=1.0 / 0.9), dict(residual=res), dict()]
+    for kw in variants:
+        got, want = ops.gemm(a, w, force_generic=mode, **kw), ops.gemm(a, w, force_generic=1, **kw)
+        assert (got.float() - want.float()).abs().max() <= 2.0 ** -6 * want.float().abs().max(), kw
+        same = (got == want).float().mean().item()
+        assert same > 0.98, (kw, same)                      # identical up to rare 1-ulp bf16 rounding flips
+    # ReLU + residual is not one of the built variants: automatic dispatch falls back, forcing it is an error
+    y = ops.gemm(a, w, bias=bias, act=ops.ACT_RELU, residual=res)
+    close(y, torch.relu(a.float() @ w.float().t() + bias.float()) + res.float())
+    with pytest.raises(Exception, match="not eligible"):
+        ops.gemm(a, w, bias=bias, act=ops.ACT_RELU, residual=res, force_generic=mode)
+
+
+def test_gemm_persistent_kernel_is_the_automatic_choice_and_deterministic(ops):
+    M, N, K = 256 * 9, 768, 768
+    g = torch.Generator(device="cuda").manual_seed(23)
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) * 0.1)
+    first = ops.gemm(a, w)
+    assert torch.equal(first, ops.gemm(a, w, force_generic=8))
+    for _ in range(5):
+        assert torch.equal(first, ops.gemm(a, w))

@@ -33,10 +33,15 @@ def main():
         a = torch.randn((k, m) if akm else (m, k), device="cuda", generator=g).bfloat16()
         b = torch.randn((k, n) if bkm else (n, k), device="cuda", generator=g).bfloat16()
         cases.append((name, m, n, k, akm, bkm, a, b))
-    modes = {"auto": 0, "generic": 1, "256x256": 7, "256x128": 6}
+    modes = {"auto": 0, "generic": 1, "256x256": 7, "256x128": 6, "torch.matmul": -1}
+
+    def run(a, b, akm, bkm, md):
+        if md == -1:      # the vendor library through torch, as a known-good yardstick on the same device (not product)
+            return torch.matmul(a.t() if akm else a, b if bkm else b.t())
+        return ops.gemm(a, b, a_kmajor=akm, b_kmajor=bkm, force_generic=md)
     for c in cases:
         for md in modes.values():
-            ops.gemm(c[6], c[7], a_kmajor=c[4], b_kmajor=c[5], force_generic=md)
+            run(c[6], c[7], c[4], c[5], md)
     torch.cuda.synchronize()
     times = {(c[0], k): [] for c in cases for k in modes}
     for _ in range(rounds):
@@ -45,7 +50,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
-                    ops.gemm(a, b, a_kmajor=akm, b_kmajor=bkm, force_generic=md)
+                    run(a, b, akm, bkm, md)
                 e1.record()
                 torch.cuda.synchronize()
                 times[(name, mk)].append(e0.elapsed_time(e1) / 3)
