@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ w
 
 int gemm256_dispatch(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s);   // gemm256.hip
 int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s);                        // gemm8p.hip
+int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_used, hipStream_t s);
 
 }  // namespace sfcvit
 
@@ -159,8 +160,17 @@ extern "C" int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream) {
 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a->force_generic == 0 || a->force_generic == 8 || a->force_generic == 9) {
-        const int p8 = gemm8p_dispatch(*a, splits, s);
+        int p8 = gemm8p_dispatch(*a, splits, s);
         if (p8 >= 0) return p8;
+        int used = 0;
+        p8 = gemm8p_km_dispatch(*a, splits, &used, s);
+        if (p8 > 0) return p8;
+        if (p8 == 0) {
+            const int64_t nvec = int64_t(a->M) * (a->N / 4);
+            hipLaunchKernelGGL(splitk_reduce, dim3(unsigned((nvec + 255) / 256)), dim3(256), 0, s,
+                               static_cast<const float *>(a->workspace), used, a->M, a->N, a->c, a->ldc, a->c_is_f32);
+            return check_launch("gemm splitk_reduce");
+        }
         if (a->force_generic != 0) return fail(SFCVIT_EINVAL, "gemm: shape / options not eligible for the persistent 8-phase kernel");
     }
     const int big = (a->force_generic == 1) ? -1 : gemm256_dispatch(*a, splits, k_per_split, s);

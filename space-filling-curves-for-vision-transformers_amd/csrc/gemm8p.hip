@@ -10,9 +10,17 @@
 //     next tile's first k-tiles under the current tile's last phases and its epilogue -- no prologue per tile.
 //   * a k-tile is 4 phases; a phase = {ds_read the fragments of one quadrant, issue the LDS-DMA of one half-tile,
 //     barrier, 16 MFMAs, barrier}.  The two wave groups run one barrier apart, so one group's MFMAs cover the other
-//     group's LDS reads and DMA issue (cdna_hip_programming.md §5, "The 256^2 8-phase template"; the staging order
-//     B0, A0, B1 of k-tile g+2 in phases 1-3 and A1 of k-tile g+1 in phase 0, one counted vmcnt(6) per k-tile in
-//     phase 3, buffers read one phase after the wait that retires them, follow its rules).
+//     group's LDS reads and DMA issue (cdna_hip_programming.md §5, "The 256^2 8-phase template").  The four
+//     half-tiles of a k-tile are cut so that each is read in exactly ONE phase -- A0 / A1 = the first 64 / the
+//     remaining rows of BOTH wave groups, B0 / B1 = the first / second 32 columns of ALL four column blocks:
+//         phase   reads (LDS)      MFMA (rows x cols)   LDS-DMA issued          counted wait before the barrier
+//           0     A0, B0           a0 x b0              A1 of k-tile g+1        -
+//           1     A1               a1 x b0              B1 of k-tile g+1        -
+//           2     B1               a1 x b1              B0 of k-tile g+2        -
+//           3     -                a0 x b1              A0 of k-tile g+2        vmcnt(4): all of k-tile g+1
+//     Every half-tile is overwritten at least two phases after its only read, so no early retirement of LDS reads is
+//     needed; two to four half-tiles (32-64 KiB per CU) are in flight at any time; a buffer is read in the phases
+//     after the wait that retires it.
 //   * LDS image of a half-tile: [128 rows][64 k] bf16, 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7)
 //     (ds_read_b128 conflict-free, tools/lds_conflicts.py); LDS-DMA writes are lane-linear, so the swizzle is
 //     applied to the per-lane SOURCE address.  B rows are stored in fragment order: LDS row 16j + l holds column
@@ -63,9 +71,9 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-struct Cursor {            // the k-tile being staged: index in this workgroup's tile list, k offset, operand origins
+struct Cursor {            // the k-tile being staged for one operand: index in the tile list, k offset, origin
     int tile, k0;
-    const uint16_t *a, *b;
+    const uint16_t *p;
 };
 
 // One output row segment of 16 consecutive columns, in the documented order: bias, act, dropout, residual, dact, store.
@@ -126,46 +134,48 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
     const int my_tiles = (ntiles - u + G - 1) / G;
 
     // --- staging: this thread's two 16-byte pieces of a half-tile (LDS rows r1 and r1 + 64) ---
+    //   A0: LDS row 64 grp + w  <-  tile row grp*GR + w            (w < 64: fragments 0-3 of wave group grp)
+    //   A1: LDS row 64 grp + w  <-  tile row grp*GR + 64 + w       (w < GR - 64; NI = 7: rows 48..63 copy 32..47, never read)
+    //   Bh: LDS row 32 wc + 16 jj + l  <-  column 64 wc + 16 (l >> 2) + 4 (2h + jj) + (l & 3): fragment order, so that a
+    //       lane's accumulators are 16 consecutive columns
     const int r1 = 8 * wid + (lane >> 3);
     const int sc = (lane & 7) ^ ((r1 >> 1) & 7);                 // source chunk that lands in LDS chunk lane & 7
-    const int b_row = ((r1 & 15) >> 2) * 16 + ((r1 >> 4) & 3) * 4 + (r1 & 3);
-    // NI = 7: a group owns 112 rows; LDS rows 112..127 are filled with a copy of rows 96..111 (never read).
-    const int a_row2 = (r1 + 64 < GR) ? r1 + 64 : r1 + 64 - 16;
-    const size_t offA1 = size_t(r1) * g.lda + sc * 8, offA2 = size_t(a_row2) * g.lda + sc * 8;
-    const size_t offB1 = size_t(b_row) * g.ldb + sc * 8, offB2 = offB1 + size_t(64) * g.ldb;
-    const size_t a_half = size_t(GR) * g.lda, b_half = size_t(128) * g.ldb;
+    const int w1 = (r1 < GR - 64) ? r1 : r1 - 16;
+    const int b_row = (r1 >> 5) * 64 + ((r1 & 15) >> 2) * 16 + ((r1 >> 4) & 1) * 4 + (r1 & 3);
+    const size_t offA0a = size_t(r1) * g.lda + sc * 8, offA0b = offA0a + size_t(GR) * g.lda;
+    const size_t offA1a = size_t(64 + w1) * g.lda + sc * 8, offA1b = offA1a + size_t(GR) * g.lda;
+    const size_t offB0a = size_t(b_row) * g.ldb + sc * 8, offB0b = offB0a + size_t(128) * g.ldb;
+    const size_t b_h1 = size_t(8) * g.ldb;
     char *const lds_piece = smem + tid * 16;
 
-    auto cursor_at = [&](int t) __attribute__((always_inline)) {
+    auto cursor_at = [&](int t, bool is_a) __attribute__((always_inline)) {
         Cursor c;
         c.tile = t;
         c.k0 = 0;
         const int tile = (t < my_tiles ? t : 0) * G + u;       // past the end: re-stage the first tile (never consumed)
-        c.a = A + size_t(tile / NT) * BM * g.lda;
-        c.b = B + size_t(tile % NT) * 256 * g.ldb;
+        c.p = is_a ? A + size_t(tile / NT) * BM * g.lda : B + size_t(tile % NT) * 256 * g.ldb;
         return c;
     };
-    auto advance = [&](Cursor &c) __attribute__((always_inline)) {
-        if (c.k0 + 64 == K) c = cursor_at(c.tile + 1);
-        else { c.k0 += 64; c.a += 64; c.b += 64; }
+    auto advance = [&](Cursor &c, bool is_a) __attribute__((always_inline)) {
+        if (c.k0 + 64 == K) c = cursor_at(c.tile + 1, is_a);
+        else { c.k0 += 64; c.p += 64; }
     };
     auto stage_a = [&](const Cursor &c, int buf, int h) __attribute__((always_inline)) {
-        const uint16_t *p = c.a + (h ? a_half : 0);
         char *d = lds_piece + buf * KTB + h * HALF;
-        __builtin_amdgcn_global_load_lds((gptr_t)(p + offA1), (lptr_t)d, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(p + offA2), (lptr_t)(d + 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(c.p + (h ? offA1a : offA0a)), (lptr_t)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(c.p + (h ? offA1b : offA0b)), (lptr_t)(d + 8192), 16, 0, 0);
     };
     auto stage_b = [&](const Cursor &c, int buf, int h) __attribute__((always_inline)) {
-        const uint16_t *p = c.b + (h ? b_half : 0);
+        const uint16_t *p = c.p + (h ? b_h1 : 0);
         char *d = lds_piece + buf * KTB + 2 * HALF + h * HALF;
-        __builtin_amdgcn_global_load_lds((gptr_t)(p + offB1), (lptr_t)d, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(p + offB2), (lptr_t)(d + 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p + offB0a), (lptr_t)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p + offB0b), (lptr_t)(d + 8192), 16, 0, 0);
     };
 
     // --- fragment reads: lane = (row nl, k chunk q) of a 16 x 32 fragment; the second k-step is the chunk ^ 4 ---
     const int o0 = nl * 128 + ((q ^ ((nl >> 1) & 7)) << 4);
-    const int a_off0 = wr * HALF + o0, a_off1 = wr * HALF + (o0 ^ 64);
-    const int b_off0 = 2 * HALF + (wc >> 1) * HALF + (wc & 1) * 8192 + o0, b_off1 = b_off0 ^ 64;
+    const int a_off0 = wr * 8192 + o0, a_off1 = wr * 8192 + (o0 ^ 64);                    // + h * HALF + 2048 i
+    const int b_off0 = 2 * HALF + wc * 4096 + o0, b_off1 = 2 * HALF + wc * 4096 + (o0 ^ 64);   // + h * HALF + 2048 jj
     bf16x8 fa0[4][2], fa1[NI - 4][2], fb0[2][2], fb1[2][2];
     auto read_a0 = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -177,15 +187,15 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
     auto read_a1 = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NI - 4; i++) {
-            fa1[i][0] = *reinterpret_cast<const bf16x8 *>(smem + a_off0 + buf * KTB + (4 + i) * 2048);
-            fa1[i][1] = *reinterpret_cast<const bf16x8 *>(smem + a_off1 + buf * KTB + (4 + i) * 2048);
+            fa1[i][0] = *reinterpret_cast<const bf16x8 *>(smem + a_off0 + buf * KTB + HALF + i * 2048);
+            fa1[i][1] = *reinterpret_cast<const bf16x8 *>(smem + a_off1 + buf * KTB + HALF + i * 2048);
         }
     };
-    auto read_b = [&](bf16x8 (&fb)[2][2], int buf, int sub) {
+    auto read_b = [&](bf16x8 (&fb)[2][2], int buf, int sub) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            fb[j][0] = *reinterpret_cast<const bf16x8 *>(smem + b_off0 + buf * KTB + (sub * 2 + j) * 2048);
-            fb[j][1] = *reinterpret_cast<const bf16x8 *>(smem + b_off1 + buf * KTB + (sub * 2 + j) * 2048);
+            fb[j][0] = *reinterpret_cast<const bf16x8 *>(smem + b_off0 + buf * KTB + sub * HALF + j * 2048);
+            fb[j][1] = *reinterpret_cast<const bf16x8 *>(smem + b_off1 + buf * KTB + sub * HALF + j * 2048);
         }
     };
 
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
             for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     // acc[i][j][r] = C[m][n]: m = row0 + 16 i + nl, n = col0 + 16 q + 4 j + r  (B rows are in fragment order)
-    auto mma0 = [&](const bf16x8 (&fb)[2][2], int bsub) {
+    auto mma0 = [&](const bf16x8 (&fb)[2][2], int bsub) __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; kk++)
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
                     acc[i][bsub * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa0[i][kk], acc[i][bsub * 2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    auto mma1 = [&](const bf16x8 (&fb)[2][2], int bsub) {
+    auto mma1 = [&](const bf16x8 (&fb)[2][2], int bsub) __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; kk++)
@@ -246,48 +256,52 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
         zero_acc();
     };
 
-    // --- prologue: k-tile 0 landed, B0 / A0 / B1 of k-tile 1 in flight ---
-    Cursor cs = cursor_at(0);
-    stage_b(cs, 0, 0); stage_a(cs, 0, 0); stage_b(cs, 0, 1); stage_a(cs, 0, 1);
-    advance(cs);
-    stage_b(cs, 1, 0); stage_a(cs, 1, 0); stage_b(cs, 1, 1);
-    wait_vm<6>();
+    // --- prologue: the state the loop expects at phase 0 of k-tile 0 ---
+    Cursor ca = cursor_at(0, true), cb = cursor_at(0, false);
+    stage_b(cb, 0, 0); stage_a(ca, 0, 0); stage_a(ca, 0, 1); stage_b(cb, 0, 1);
+    advance(ca, true);
+    advance(cb, false);
+    stage_b(cb, 1, 0); stage_a(ca, 1, 0);
+    wait_vm<4>();                             // k-tile 0
     bar();
     if (wr == 1) bar();                       // wave group 1 runs one barrier behind group 0
     zero_acc();
 
-    // One k-tile.  `cs` is k-tile g+1 in phase 0 (its A1 is the only half-tile not issued yet) and g+2 afterwards.
+    // One k-tile g in buffer `buf`.  On entry `ca` and `cb` are k-tile g+1 (its A0 / B0 already issued).
+    // One counted wait per k-tile (phase 3, vmcnt(4): everything but the two half-tiles issued last has landed, i.e.
+    // the whole next k-tile).  Waiting per half-tile just before its first use (vmcnt(8) in phases 0, 1 and 3) measured
+    // 2-5 % slower in the same process; it also keeps the epilogue's stores -- vector-memory operations that retire
+    // in order with the LDS-DMA -- three phases away from the next wait.
     auto ktile = [&](int buf, bool last, int t) __attribute__((always_inline)) {
-        // phase 0: rows 0-63 x columns 0-31 of the wave tile
+        // phase 0: a0 x b0
         read_b(fb0, buf, 0);
-        __builtin_amdgcn_sched_barrier(0);
         read_a0(buf);
-        stage_a(cs, buf ^ 1, 1);
-        advance(cs);
-        wait_lgkm<8>();                       // B0 of this buffer has been read: it is restaged in phase 1
+        stage_a(ca, buf ^ 1, 1);
+        advance(ca, true);
         bar();
         wait_lgkm<0>();
         mma0(fb0, 0);
         bar();
-        // phase 1: rows 0-63 x columns 32-63
-        read_b(fb1, buf, 1);
-        stage_b(cs, buf, 0);
+        // phase 1: a1 x b0
+        read_a1(buf);
+        stage_b(cb, buf ^ 1, 1);
+        advance(cb, false);
         bar();
         wait_lgkm<0>();
-        mma0(fb1, 1);
+        mma1(fb0, 0);
         bar();
-        // phase 2: rows 64.. x columns 32-63
-        read_a1(buf);
-        stage_a(cs, buf, 0);
+        // phase 2: a1 x b1
+        read_b(fb1, buf, 1);
+        stage_b(cb, buf, 0);
         bar();
         wait_lgkm<0>();
         mma1(fb1, 1);
         bar();
-        // phase 3: rows 64.. x columns 0-31; the other buffer (k-tile g+1) lands before anyone reads it in the next phase
-        stage_b(cs, buf, 1);
-        wait_vm<6>();
+        // phase 3: a0 x b1
+        stage_a(ca, buf, 0);
+        wait_vm<4>();                         // the whole next k-tile has landed
         bar();
-        mma1(fb0, 0);
+        mma0(fb1, 1);
         if (last && wr == 1) epilogue(t);
         bar();
         if (last && wr == 0) epilogue(t);
@@ -303,6 +317,182 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
     }
     if (wr == 0) bar();
     wait_vm<0>();
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------
+// Weight-gradient form: C[M,N] = sum_k A[k][m] B[k][n] (both operands k-major: dW = dY^T X with k = token rows).
+// Same 8 phases and ring; what changes is the LDS image and the fragment reads:
+//   * half-tile = [64 k][128 cols] bf16 (256-B rows, the "st" image of device_common.h: 32-byte chunk index XOR-ed
+//     with (k & 3) | ((k >> 3) & 1) << 2), filled by LDS-DMA in 4-row x 256-B pieces (two full cache lines per row)
+//     with the swizzle on the source address;
+//   * a 16 x 32 fragment is two ds_read_b64_tr_b16 (the hardware transposes 4 k-rows x 16 columns per 16-lane
+//     group), conflict-free on that image.
+// The output has few tiles (9-36 for ViT-B) and a very long k (batch x tokens), so the launch is tiles x splits
+// workgroups, each with one k-range, writing its fp32 partial tile to slab z of the workspace; sfcvit_gemm's ordered
+// split-K reduction sums the slabs (deterministic, no atomics).
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(T) void gemm8p_km_kernel(const sfcvit_gemm_args g, int kt_per_split, int nsplits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3;
+    const int q4 = lane >> 4, nl = lane & 15;
+    const int NT = g.N / 256, KT = g.K / 64;
+    const int tiles = (g.M / 256) * NT;
+    // unit = (k-range z, tile), z major.  The workgroups of an XCD (blockIdx % 8) take a contiguous chunk of the unit
+    // list: they run the same k-range at the same time, so every A / B panel is fetched from HBM once per XCD
+    // (tile-minor round-robin instead re-read dY 3x and X 12x: 1.85 GB for 385 MB of operands).
+    const int unit = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (unit >= tiles * nsplits) return;
+    const int tile = unit % tiles, z = unit / tiles;
+    const int m0 = (tile / NT) * 256, n0 = (tile % NT) * 256;
+    const int kt_beg = z * kt_per_split;
+    const int nkt = min(kt_per_split, KT - kt_beg);            // even, >= 2 (host)
+    const uint16_t *A = static_cast<const uint16_t *>(g.a) + size_t(kt_beg) * 64 * g.lda + m0;
+    const uint16_t *B = static_cast<const uint16_t *>(g.b) + size_t(kt_beg) * 64 * g.ldb + n0;
+
+    // --- staging: this thread's two 16-byte pieces of a half-tile (k-rows kr and kr + 32, 16-byte chunk lane & 15) ---
+    const int kr = 4 * wid + (lane >> 4);
+    const int sw = (kr & 3) | (((kr >> 3) & 1) << 2);
+    const int c16 = ((((lane & 15) >> 1) ^ sw) << 1) | (lane & 1);       // source chunk that lands in LDS chunk lane & 15
+    const size_t offA = size_t(kr) * g.lda + c16 * 8, offB = size_t(kr) * g.ldb + c16 * 8;
+    const size_t a32 = size_t(32) * g.lda, b32 = size_t(32) * g.ldb, a64 = size_t(64) * g.lda, b64 = size_t(64) * g.ldb;
+    char *const lds_piece = smem + tid * 16;
+    const uint16_t *ca = A, *cb = B;                            // k-tiles being staged
+    int akt = 0, bkt = 0;
+    auto advance_a = [&]() __attribute__((always_inline)) {
+        if (++akt < nkt) ca += a64;                             // past the end: keep re-staging the last k-tile (never consumed)
+    };
+    auto advance_b = [&]() __attribute__((always_inline)) {
+        if (++bkt < nkt) cb += b64;
+    };
+    auto stage_a = [&](int buf, int h) __attribute__((always_inline)) {
+        const uint16_t *p = ca + offA + h * 128;
+        char *d = lds_piece + buf * KTB + h * HALF;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p + a32), (lptr_t)(d + 8192), 16, 0, 0);
+    };
+    auto stage_b = [&](int buf, int h) __attribute__((always_inline)) {
+        const uint16_t *p = cb + offB + h * 128;
+        char *d = lds_piece + buf * KTB + 2 * HALF + h * HALF;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p + b32), (lptr_t)(d + 8192), 16, 0, 0);
+    };
+
+    // --- transposed fragment reads: lane group (q4, nl>>2) reads 8 bytes of k-row 8 q4 + (nl>>2) (and + 4) at
+    //     columns 16 c + 4 (nl & 3); the chunk swizzle of that row is q | (q4 & 1) << 2 ---
+    const int qq = nl >> 2, pp = nl & 3;
+    const int lane_sw = qq | ((q4 & 1) << 2);
+    const int row_off = (8 * q4 + qq) * 256 + 8 * pp;
+    int a_addr[8], b_addr[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)      // fragment i = 4 asub + ii: columns 64 wr + 16 ii of A half asub
+        a_addr[i] = (i >> 2) * HALF + row_off + (((wr * 4 + (i & 3)) ^ lane_sw) << 5);
+#pragma unroll
+    for (int j = 0; j < 4; j++)      // fragment j = 2 bsub + jj: columns 32 wc + 16 jj of B half bsub
+        b_addr[j] = 2 * HALF + (j >> 1) * HALF + row_off + (((wc * 2 + (j & 1)) ^ lane_sw) << 5);
+    // The reads are inline asm on purpose: for the ds_read_tr builtin hipcc (ROCm 7.2) cannot tell which LDS bytes
+    // are read and puts `s_waitcnt vmcnt(0)` in front of every group of them while an LDS-DMA is in flight, which
+    // drains the whole prefetch ring four times per k-tile (measured: 550 instead of 730 TFLOP/s).  The compiler
+    // therefore does not know when the data arrives: every use sits behind wait_lgkm<0>() + sched_barrier.
+    // LDS addresses carry the ring buffer in bit 16 and are flipped once per k-tile (DS offsets are 16 bits).
+#define SFCVIT_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+    auto tr_frag2 = [&](bf16x8 (&f)[2], int addr) __attribute__((always_inline)) {      // both k-steps of one fragment
+        bf16x4 l0, h0, l1, h1;
+        SFCVIT_TR(l0, addr, 0);
+        SFCVIT_TR(h0, addr, 1024);
+        SFCVIT_TR(l1, addr, 8192);
+        SFCVIT_TR(h1, addr, 9216);
+        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    bf16x8 fa0[4][2], fa1[4][2], fb0[2][2], fb1[2][2];
+    auto read_a2 = [&](bf16x8 (&fa)[4][2], int sub, int i0) __attribute__((always_inline)) {   // fragments i0, i0+1
+#pragma unroll
+        for (int i = i0; i < i0 + 2; i++) tr_frag2(fa[i], a_addr[sub * 4 + i]);
+    };
+    auto read_b = [&](bf16x8 (&fb)[2][2], int sub) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) tr_frag2(fb[j], b_addr[sub * 2 + j]);
+    };
+    auto flip = [&]() __attribute__((always_inline)) {           // the next k-tile lives in the other ring buffer
+#pragma unroll
+        for (int i = 0; i < 8; i++) a_addr[i] ^= KTB;
+#pragma unroll
+        for (int j = 0; j < 4; j++) b_addr[j] ^= KTB;
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2], int asub, int bsub) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[asub * 4 + i][bsub * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[asub * 4 + i][bsub * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    stage_b(0, 0); stage_a(0, 0); stage_a(0, 1); stage_b(0, 1);
+    advance_a();
+    advance_b();
+    stage_b(1, 0); stage_a(1, 0);
+    wait_vm<4>();
+    bar();
+    if (wr == 1) bar();
+    // same schedule as gemm8p_kernel (table at the top of the file); the half-tiles are contiguous 128-column blocks
+    // here, and a wave takes its a0 / a1 (b0 / b1) fragments from the first / second of them
+    auto ktile = [&](int buf) __attribute__((always_inline)) {
+        read_b(fb0, 0);
+        read_a2(fa0, 0, 0);
+        read_a2(fa0, 0, 2);
+        stage_a(buf ^ 1, 1);
+        advance_a();
+        bar();
+        wait_lgkm<0>();
+        mma(fa0, fb0, 0, 0);
+        bar();
+        read_a2(fa1, 1, 0);
+        read_a2(fa1, 1, 2);
+        stage_b(buf ^ 1, 1);
+        advance_b();
+        bar();
+        wait_lgkm<0>();
+        mma(fa1, fb0, 1, 0);
+        bar();
+        read_b(fb1, 1);
+        stage_b(buf, 0);
+        bar();
+        wait_lgkm<0>();
+        mma(fa1, fb1, 1, 1);
+        bar();
+        stage_a(buf, 0);
+        wait_vm<4>();
+        bar();
+        mma(fa0, fb1, 0, 1);
+        bar();
+        flip();
+    };
+    for (int k = 0; k < nkt; k += 2) {
+        ktile(0);
+        ktile(1);
+    }
+    if (wr == 0) bar();
+    wait_vm<0>();
+    mfma_fence();
+    // acc[4 as + ii][2 bs + jj][r] = C[m0 + 128 as + 64 wr + 16 ii + nl][n0 + 128 bs + 32 wc + 16 jj + 4 q4 + r]
+    float *slab = static_cast<float *>(g.workspace) + size_t(z) * g.M * g.N + size_t(m0 + wr * 64 + nl) * g.N + n0 + wc * 32 + 4 * q4;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<f32x4 *>(slab + size_t((i >> 2) * 128 + (i & 3) * 16) * g.N + (j >> 1) * 128 + (j & 1) * 16) = acc[i][j];
 }
 
 template <int NI, int MASK>
@@ -333,6 +523,40 @@ int launch_mask(const sfcvit_gemm_args &a, int mask, int grid, hipStream_t s) {
 
 }  // namespace p8
 }  // namespace
+
+// Weight-gradient form (both operands k-major, split-K into the workspace slabs).  Returns -1 when not eligible,
+// else a status; *splits_used = number of slabs written (the caller runs the ordered reduction over them).
+int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_used, hipStream_t s) {
+    using namespace p8;
+    if (!a.a_kmajor || !a.b_kmajor || splits_req < 2) return -1;
+    if (a.M % 256 || a.N % 256 || a.K % 128 || a.lda % 8 || a.ldb % 8) return -1;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        cus = prop.multiProcessorCount;
+    }
+    const int tiles = (a.M / 256) * (a.N / 256), KT = a.K / 64;
+    int splits = cus / tiles;                                     // one workgroup per CU
+    if (splits > splits_req) splits = splits_req;
+    const int64_t slabs_avail = a.workspace_bytes / (int64_t(a.M) * a.N * int64_t(sizeof(float)));
+    if (splits > slabs_avail) splits = int(slabs_avail);
+    if (splits < 2) return -1;
+    int kps = ((KT + splits - 1) / splits + 1) / 2 * 2;           // k-tiles per split, even
+    splits = (KT + kps - 1) / kps;
+    if (splits < 2) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8p_km_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess)
+            return check_launch("gemm8p_km attribute");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm8p_km_kernel, dim3((tiles * splits + 7) / 8 * 8), dim3(T), LDS_BYTES, s, a, kps, splits);
+    *splits_used = splits;
+    return check_launch("gemm8p_km");
+}
 
 // Called by sfcvit_gemm after argument validation.  -1 = not eligible (the caller tries the older kernels).
 int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {

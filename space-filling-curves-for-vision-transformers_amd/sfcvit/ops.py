@@ -94,6 +94,11 @@ def auto_splitk(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 256 or K < 2048:
         return 1
+    if M % 256 == 0 and N % 256 == 0 and K % 128 == 0:
+        # weight-gradient form of the 8-phase kernel: one workgroup per CU, tiles256 x splits <= 256
+        s = min(64, 256 // ((M // 256) * (N // 256)))
+        if s >= 2 and K // s >= 512:
+            return s
     step = 8 if tiles < 64 else 1
     best, best_eff = 1, tiles / 512.0 if tiles < 512 else 1.0
     for s in range(max(2, step), 65, step):

@@ -367,3 +367,28 @@ def test_gemm_persistent_kernel_is_the_automatic_choice_and_deterministic(ops):
     assert torch.equal(first, ops.gemm(a, w, force_generic=8))
     for _ in range(5):
         assert torch.equal(first, ops.gemm(a, w))
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 256, 4096, 4), (512, 768, 8192, 8), (768, 768, 50176, None),
+                                          (768, 2304, 12544, None), (256, 512, 640, 2), (256, 256, 1024 + 128, 3)])
+def test_gemm_weight_gradient_8phase_kernel(ops, M, N, K, splitk):
+    """dW = dY^T X with both operands k-major: the split-K 8-phase kernel (automatic choice for these shapes)
+    against fp32 math, and run-to-run bit-identical (ordered slab reduction, no atomics)."""
+    g = torch.Generator(device="cuda").manual_seed(31)
+    a = bf(torch.randn(K, M, device="cuda", generator=g))
+    b = bf(torch.randn(K, N, device="cuda", generator=g))
+    ref = a.float().t() @ b.float()
+    c = ops.gemm(a, b, a_kmajor=True, b_kmajor=True, splitk=splitk)
+    close(c, ref)
+    c32 = ops.gemm(a, b, a_kmajor=True, b_kmajor=True, splitk=splitk, out_f32=True)
+    close(c32, ref, rel=2e-3, abs_scale=2e-3)
+    assert torch.equal(c, ops.gemm(a, b, a_kmajor=True, b_kmajor=True, splitk=splitk))
+    if splitk is not None:
+        assert torch.equal(c, ops.gemm(a, b, a_kmajor=True, b_kmajor=True, splitk=splitk, force_generic=8))
+    # asymmetric check: a one-hot A picks single rows of B (catches a transposed or permuted fragment map)
+    a1 = torch.zeros(K, M, device="cuda", dtype=torch.bfloat16)
+    idx = torch.randint(0, K, (M,), device="cuda", generator=g)
+    a1[idx, torch.arange(M, device="cuda")] = 1
+    want = torch.zeros(M, N, device="cuda")
+    want.index_add_(0, torch.arange(M, device="cuda"), b.float()[idx])
+    assert torch.equal(ops.gemm(a1, b, a_kmajor=True, b_kmajor=True, splitk=splitk).float(), want.bfloat16().float())

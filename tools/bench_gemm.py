@@ -33,7 +33,7 @@ def main():
         a = torch.randn((k, m) if akm else (m, k), device="cuda", generator=g).bfloat16()
         b = torch.randn((k, n) if bkm else (n, k), device="cuda", generator=g).bfloat16()
         cases.append((name, m, n, k, akm, bkm, a, b))
-    modes = {"auto": 0, "generic": 1, "256x256": 7, "256x128": 6, "torch.matmul": -1}
+    modes = {"auto": 0, "generic": 1, "ring 256x128": 6, "torch.matmul": -1}
 
     def run(a, b, akm, bkm, md):
         if md == -1:      # the vendor library through torch, as a known-good yardstick on the same device (not product)
