@@ -182,10 +182,9 @@ def main():
             dom = max(kern, key=lambda k: kern[k]["ms_total"])
             r = kern[dom]
             ach = r["work_total"] / (r["ms_total"] * 1e-3) / 1e12
-            # rocprofv3 symbol of the launches behind each timing key (for the committed profiles/ summaries)
-            symbol = {"gemm y=x.W^T (k-contig, k-contig)": "gemm256_kernel<false,false,128,false>",
-                      "gemm dW=dy^T.x (k-major, k-major)": "gemm_kernel<true,true,false>",
-                      "gemm dx=dy.W (k-contig, k-major)": "gemm_kernel<false,true,false>"}.get(dom, dom)
+            # GEMM timing keys are "gemm <kernel symbol>" (sfcvit_last_gemm_kernel): the name rocprofv3 shows for the
+            # same launches in profiles/ (there prefixed with the namespace).
+            symbol = dom[5:] if dom.startswith("gemm ") else dom
             traffic = None                          # PMC counters cannot be read live: offline passes, see profiles/traffic.json
             try:
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:

@@ -147,6 +147,9 @@ typedef struct sfcvit_gemm_args {
 } sfcvit_gemm_args;
 
 int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);
+/* HOST: name of the kernel the calling thread's last sfcvit_gemm launched, as rocprofv3 prints it (without the
+ * namespace), e.g. "gemm8p_kernel<7, 6>" -- lets a benchmark key its live timings by kernel symbol. */
+int sfcvit_last_gemm_kernel(char *buf, int n);
 /* HOST: bytes of workspace sfcvit_gemm needs for this split (0 when splitk <= 1). */
 int64_t sfcvit_gemm_workspace(int M, int N, int splitk);
 

@@ -5,6 +5,11 @@
 namespace sfcvit {
 namespace {
 thread_local char g_err[512] = "";
+thread_local int g_gemm[5] = {0, 0, 0, 0, 0};
+}
+
+void note_gemm_kernel(int family, int a, int b, int c, int d) {
+    g_gemm[0] = family; g_gemm[1] = a; g_gemm[2] = b; g_gemm[3] = c; g_gemm[4] = d;
 }
 
 int fail(int code, const char *fmt, ...) {
@@ -28,6 +33,20 @@ int check_launch(const char *what) {
 extern "C" int sfcvit_abi_version(void) { return SFCVIT_ABI_VERSION; }
 
 extern "C" const char *sfcvit_last_error(void) { return sfcvit::g_err; }
+
+extern "C" int sfcvit_last_gemm_kernel(char *buf, int n) {
+    using sfcvit::g_gemm;
+    if (!buf || n <= 0) return SFCVIT_EINVAL;
+    const char *tf[2] = {"false", "true"};
+    switch (g_gemm[0]) {
+    case 1: snprintf(buf, size_t(n), "gemm8p_kernel<%d, %d>", g_gemm[1], g_gemm[2]); break;
+    case 2: snprintf(buf, size_t(n), "gemm8p_km_kernel"); break;
+    case 3: snprintf(buf, size_t(n), "gemm256_kernel<%s, %s, %d, %s>", tf[g_gemm[1] & 1], tf[g_gemm[2] & 1], g_gemm[3], tf[g_gemm[4] & 1]); break;
+    case 4: snprintf(buf, size_t(n), "gemm_kernel<%s, %s, %s>", tf[g_gemm[1] & 1], tf[g_gemm[2] & 1], tf[g_gemm[3] & 1]); break;
+    default: snprintf(buf, size_t(n), "none"); break;
+    }
+    return SFCVIT_OK;
+}
 
 extern "C" int sfcvit_device_count(void) {
     int n = 0;

@@ -14,6 +14,10 @@ void clear_error();
 // hipGetLastError() -> SFCVIT_ELAUNCH with the HIP message, or SFCVIT_OK.
 int check_launch(const char *what);
 
+// Which GEMM kernel the calling thread's last sfcvit_gemm launched (sfcvit_last_gemm_kernel formats it as the symbol
+// rocprofv3 shows): family 1 gemm8p_kernel<a, b>, 2 gemm8p_km_kernel, 3 gemm256_kernel<a, b, c, d>, 4 gemm_kernel<a, b, c>.
+void note_gemm_kernel(int family, int a = 0, int b = 0, int c = 0, int d = 0);
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace sfcvit

@@ -183,6 +183,7 @@ extern "C" int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream) {
         if (heavy) hipLaunchKernelGGL((gemm_kernel<AK, BK, true>), grid, block, lds, s, *a, k_per_split, splits);   \
         else hipLaunchKernelGGL((gemm_kernel<AK, BK, false>), grid, block, lds, s, *a, k_per_split, splits);        \
     } while (0)
+    if (big != 0) note_gemm_kernel(4, a->a_kmajor != 0, a->b_kmajor != 0, heavy);
     if (big == 0) {
     } else if (!a->a_kmajor && !a->b_kmajor) SFCVIT_GO(false, false);
     else if (!a->a_kmajor && a->b_kmajor) SFCVIT_GO(false, true);

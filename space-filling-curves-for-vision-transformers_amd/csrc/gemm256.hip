@@ -199,6 +199,7 @@ int launch1(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t 
         attr_set = true;
     }
     dim3 grid((a.M / 256) * (a.N / BN_), 1, splits), block(Cfg<BN_>::T);
+    note_gemm_kernel(3, A_KM, B_KM, BN_, HEAVY);
     hipLaunchKernelGGL((gemm256_kernel<A_KM, B_KM, BN_, HEAVY>), grid, block, lds, s, a, k_per_split);
     return check_launch("gemm256");
 }

@@ -271,7 +271,10 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
     // One counted wait per k-tile (phase 3, vmcnt(4): everything but the two half-tiles issued last has landed, i.e.
     // the whole next k-tile).  Waiting per half-tile just before its first use (vmcnt(8) in phases 0, 1 and 3) measured
     // 2-5 % slower in the same process; it also keeps the epilogue's stores -- vector-memory operations that retire
-    // in order with the LDS-DMA -- three phases away from the next wait.
+    // in order with the LDS-DMA -- three phases away from the next wait.  Also measured and not kept: issuing each
+    // phase's fragment reads one phase early, under the previous phase's MFMAs (role-swapping register sets): no
+    // gain (1051 / 813 / 977 / 1073 vs 1043 / 819 / 985 / 1116 TFLOP/s on the four forward shapes) and spills at
+    // 256 registers -- LDS read latency is not what the load section of a phase waits for.
     auto ktile = [&](int buf, bool last, int t) __attribute__((always_inline)) {
         // phase 0: a0 x b0
         read_b(fb0, buf, 0);
@@ -504,6 +507,7 @@ int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
             return check_launch("gemm8p attribute");
         attr_set = true;
     }
+    note_gemm_kernel(1, NI, MASK);
     hipLaunchKernelGGL((gemm8p_kernel<NI, MASK>), dim3(grid), dim3(T), LDS_BYTES, s, a);
     return check_launch("gemm8p");
 }
@@ -553,6 +557,7 @@ int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_us
             return check_launch("gemm8p_km attribute");
         attr_set = true;
     }
+    note_gemm_kernel(2);
     hipLaunchKernelGGL(gemm8p_km_kernel, dim3((tiles * splits + 7) / 8 * 8), dim3(T), LDS_BYTES, s, a, kps, splits);
     *splits_used = splits;
     return check_launch("gemm8p_km");

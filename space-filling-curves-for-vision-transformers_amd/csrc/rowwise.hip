@@ -241,14 +241,23 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(const uint16_t *__restr
     }
 }
 
-// out[c] = sum over row blocks, in row-block order (no float atomics: the sum is reproducible)
+// out[c] = sum over row blocks in a fixed order (no float atomics: bit-reproducible).  A block owns 32 columns;
+// its 8 thread rows each add every 8th partial, then the 8 sub-sums are added in order.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ part, int nparts, int N,
                                                             float *__restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    __shared__ float red[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), s = threadIdx.x >> 5;
     float t = 0.f;
-    for (int y = 0; y < nparts; y++) t += part[size_t(y) * N + c];
-    out[c] = t;
+    if (c < N)
+        for (int y = s; y < nparts; y += 8) t += part[size_t(y) * N + c];
+    red[s][threadIdx.x & 31] = t;
+    __syncthreads();
+    if (s == 0 && c < N) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) r += red[k][threadIdx.x];
+        out[c] = r;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -567,7 +576,8 @@ extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *
 namespace {
 void colsum_plan(int M, int N, int &col_blocks, int &row_blocks, int &rpb) {
     col_blocks = (N + 255) / 256;
-    row_blocks = 2048 / col_blocks;
+    row_blocks = 1024 / col_blocks;          // ~1024 workgroups in the first pass; the partials stay a few MB
+    if (row_blocks > 256) row_blocks = 256;
     if (row_blocks < 1) row_blocks = 1;
     rpb = (M + row_blocks - 1) / row_blocks;
     rpb = ((rpb + 7) / 8) * 8;
@@ -596,7 +606,7 @@ extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, vo
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(THREADS), 0, s,
                        static_cast<const uint16_t *>(x), M, N, ld, rpb, part);
     if (int rc = check_launch("colsum")) return rc;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(col_blocks), dim3(256), 0, s, part, row_blocks, N, out);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, part, row_blocks, N, out);
     return check_launch("colsum reduce");
 }
 

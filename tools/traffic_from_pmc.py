@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) over
+`bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing` into profiles/traffic.json: HBM-side bytes per
+launch for every sfcvit kernel.  rocprofv3 reports both counters in KiB; FETCH_SIZE is doubled (on gfx950 it tallies
+the 128-B requests of 16-B/lane streaming reads as 64 B, MI355X_MICROARCH.md "HBM"), WRITE_SIZE is taken as is.
+
+    python tools/traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <build tag>
+"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_kernel(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"]
+            name = re.sub(r"^void ", "", name)
+            name = name.replace("sfcvit::(anonymous namespace)::", "").replace("p8::", "")
+            name = re.sub(r"\(.*$", "", name)
+            tot[name] += float(row["Counter_Value"])
+            cnt[name] += 1
+    return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"_comment": "HBM-side traffic per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                       "passes over `bench.py --steps 3 --warmup 1`), averaged over all launches of the kernel. bytes = counter "
+                       "value x 1024; FETCH_SIZE is then doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streaming "
+                       "reads on gfx950 (128-B requests tallied as 64 B); WRITE_SIZE is taken as is. Infinity-Cache hits "
+                       "are included in FETCH_SIZE.",
+           "build": sys.argv[3] if len(sys.argv) > 3 else "", "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        if not ("gemm" in k or "attn" in k or "ln_" in k or "pe_" in k or "adamw" in k or "colsum" in k or "transpose" in k):
+            continue
+        f, nf = fetch.get(k, (0.0, 0))
+        w, _ = write.get(k, (0.0, 0))
+        out["kernels"][k] = {"fetch_bytes_raw": f * 1024, "fetch_bytes_corrected": 2 * f * 1024, "write_bytes": w * 1024,
+                             "traffic_bytes": 2 * f * 1024 + w * 1024, "launches_sampled": nf}
+    with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as fo:
+        json.dump(out, fo, indent=1)
+    for k, v in out["kernels"].items():
+        print(f"{k:60s} {v['traffic_bytes'] / 1e6:10.1f} MB/launch ({v['launches_sampled']} launches)")
+
+
+if __name__ == "__main__":
+    main()
