@@ -161,7 +161,8 @@ int sfcvit_transpose(const void *src, int R, int C, int lds, void *dst, int ldd,
  * Two passes through `workspace` (sfcvit_colsum_workspace bytes, HOST query) instead of float atomics, so the
  * result is bit-reproducible from run to run. */
 int64_t sfcvit_colsum_workspace(int M, int N);
-int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *workspace, int64_t workspace_bytes, void *stream);
+int sfcvit_colsum(const void *x, int M, int N, int ld, void *out, int out_bf16, void *workspace, int64_t workspace_bytes,
+                  void *stream);   /* out: fp32 [N], or bf16 [N] when out_bf16 != 0 */
 
 /* ------------------------------------------------------------------------
  * LayerNorm (biased variance, affine) -- nn.LayerNorm at norm1/norm2
@@ -183,8 +184,10 @@ int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const
  * bias gradient of the sub-layer's last Linear, for free in the same pass. */
 int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, const float *rstd,
                               const void *gamma, const void *dx_add, void *dx, void *dx_drop, float p,
-                              uint32_t seed, float *dgamma, float *dbeta, float *dcol, int M, int D,
+                              uint32_t seed, void *dgamma, void *dbeta, void *dcol, int grads_bf16, int M, int D,
                               void *ws, void *stream);
+/* grads_bf16 != 0: dgamma / dbeta / dcol are bf16 [D] instead of fp32 -- the caller passes views of its flat
+ * gradient buffer and no cast / accumulate pass follows. */
 int64_t sfcvit_layernorm_bwd_ws(int M, int D);
 
 /* ------------------------------------------------------------------------

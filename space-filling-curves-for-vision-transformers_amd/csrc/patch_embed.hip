@@ -284,6 +284,6 @@ extern "C" int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *st
                        static_cast<float *>(a->dw), a->D, a->C, a->P, g.Kp);
     if (int rc = check_launch("patch_embed_bwd reduce")) return rc;
     if (a->dbias)
-        return sfcvit_colsum(a->y, g.M, a->D, a->D, static_cast<float *>(a->dbias), a->workspace, a->workspace_bytes, stream);
+        return sfcvit_colsum(a->y, g.M, a->D, a->D, a->dbias, 0, a->workspace, a->workspace_bytes, stream);
     return SFCVIT_OK;
 }

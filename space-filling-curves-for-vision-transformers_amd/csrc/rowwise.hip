@@ -184,8 +184,14 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
 
 // Sum of the per-block partials [nblocks][3][D] (dgamma | dbeta | column sums of the outgoing
 // gradient): 16 columns x 16 partial-groups per block, fixed summation order (bitwise reproducible).
-__global__ __launch_bounds__(256) void ln_bwd_reduce(const float *__restrict__ partial, float *__restrict__ dgamma,
-                                                    float *__restrict__ dbeta, float *__restrict__ dcol, int nblocks, int D) {
+__device__ __forceinline__ void store_grad(void *p, int i, float v, int as_bf16) {
+    if (as_bf16) static_cast<uint16_t *>(p)[i] = f2bf(v);
+    else static_cast<float *>(p)[i] = v;
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float *__restrict__ partial, void *__restrict__ dgamma,
+                                                    void *__restrict__ dbeta, void *__restrict__ dcol, int nblocks, int D,
+                                                    int as_bf16) {
     __shared__ float red[16][17];
     const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -198,9 +204,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float *__restrict__ p
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) t += red[k][cl];
-        if (c < D) dgamma[c] = t;
-        else if (c < 2 * D) dbeta[c - D] = t;
-        else if (dcol) dcol[c - 2 * D] = t;
+        if (c < D) store_grad(dgamma, c, t, as_bf16);
+        else if (c < 2 * D) store_grad(dbeta, c - D, t, as_bf16);
+        else if (dcol) store_grad(dcol, c - 2 * D, t, as_bf16);
     }
 }
 
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(const uint16_t *__restr
 // out[c] = sum over row blocks in a fixed order (no float atomics: bit-reproducible).  A block owns 32 columns;
 // its 8 thread rows each add every 8th partial, then the 8 sub-sums are added in order.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ part, int nparts, int N,
-                                                            float *__restrict__ out) {
+                                                            void *__restrict__ out, int as_bf16) {
     __shared__ float red[8][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), s = threadIdx.x >> 5;
     float t = 0.f;
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
         float r = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; k++) r += red[k][threadIdx.x];
-        out[c] = r;
+        store_grad(out, c, r, as_bf16);
     }
 }
 
@@ -539,8 +545,8 @@ extern "C" int64_t sfcvit_layernorm_bwd_ws(int M, int D) {
 
 extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, const float *rstd,
                                          const void *gamma, const void *dx_add, void *dx, void *dx_drop, float p,
-                                         uint32_t seed, float *dgamma, float *dbeta, float *dcol, int M, int D,
-                                         void *ws, void *stream) {
+                                         uint32_t seed, void *dgamma, void *dbeta, void *dcol, int grads_bf16, int M,
+                                         int D, void *ws, void *stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !ws)
         return fail(SFCVIT_EINVAL, "layernorm_bwd: null pointer");
     if (M <= 0 || D <= 0 || D % 8 || D > 2048) return fail(SFCVIT_EINVAL, "layernorm_bwd: M=%d D=%d (D %% 8 == 0, D <= 2048)", M, D);
@@ -563,14 +569,14 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
     else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
     if (int rc = check_launch("layernorm_bwd")) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((3 * D + 15) / 16), dim3(256), 0, s, part, dgamma, dbeta, dcol, nb, D);
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((3 * D + 15) / 16), dim3(256), 0, s, part, dgamma, dbeta, dcol, nb, D, grads_bf16);
     return check_launch("layernorm_bwd_reduce");
 }
 
 extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const float *rstd,
                                     const void *gamma, const void *dx_add, void *dx, float *dgamma, float *dbeta,
                                     int M, int D, void *ws, void *stream) {
-    return sfcvit_layernorm_bwd_drop(dy, x, mean, rstd, gamma, dx_add, dx, nullptr, 0.f, 0u, dgamma, dbeta, nullptr, M, D, ws, stream);
+    return sfcvit_layernorm_bwd_drop(dy, x, mean, rstd, gamma, dx_add, dx, nullptr, 0.f, 0u, dgamma, dbeta, nullptr, 0, M, D, ws, stream);
 }
 
 namespace {
@@ -592,8 +598,8 @@ extern "C" int64_t sfcvit_colsum_workspace(int M, int N) {
     return int64_t(rb) * N * int64_t(sizeof(float));
 }
 
-extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, void *workspace, int64_t workspace_bytes,
-                             void *stream) {
+extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, void *out, int out_bf16, void *workspace,
+                             int64_t workspace_bytes, void *stream) {
     if (!x || !out) return fail(SFCVIT_EINVAL, "colsum: null pointer");
     if (M <= 0 || N <= 0 || N % 8 || ld % 8 || ld < N) return fail(SFCVIT_EINVAL, "colsum: M=%d N=%d ld=%d (N, ld %% 8 == 0)", M, N, ld);
     if (!aligned16(x)) return fail(SFCVIT_EINVAL, "colsum: alignment");
@@ -606,7 +612,7 @@ extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, float *out, vo
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(THREADS), 0, s,
                        static_cast<const uint16_t *>(x), M, N, ld, rpb, part);
     if (int rc = check_launch("colsum")) return rc;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, part, row_blocks, N, out);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, part, row_blocks, N, out, out_bf16);
     return check_launch("colsum reduce");
 }
 

@@ -64,14 +64,14 @@ SIGNATURES = {
     "sfcvit_transpose": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sfcvit_last_gemm_kernel": (c_int, [ctypes.c_char_p, c_int]),
     "sfcvit_colsum_workspace": (c_int64, [c_int, c_int]),
-    "sfcvit_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sfcvit_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "sfcvit_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_float, c_void_p]),
     "sfcvit_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sfcvit_layernorm_bwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_float, ctypes.c_uint32, c_void_p, c_void_p,
-                                          c_void_p, c_int, c_int, c_void_p, c_void_p]),
+                                          c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sfcvit_layernorm_bwd_ws": (c_int64, [c_int, c_int]),
     "sfcvit_gelu_drop_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p]),
     "sfcvit_gelu_drop_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p]),

@@ -32,9 +32,26 @@ def _like(g, ref):
     return g if g.dtype == ref.dtype else g.to(ref.dtype)
 
 
-def _wgrad(dy2, x2):
-    """dW[out, in] = dY^T X  (contraction over rows; both operands k-major)."""
-    return ops.gemm(dy2, x2, a_kmajor=True, b_kmajor=True)
+def _slot(p):
+    """A fresh view of parameter `p`'s place in its optimizer's flat gradient buffer (FlatGradBuffer.slots), or None.
+    Kernels write the gradient there directly and return the view: autograd, finding p.grad unset, adopts it as
+    p.grad without a copy -- no fp32 -> bf16 cast and no `p.grad += g` pass per parameter (146 + 106 tiny kernels per
+    ViT-B step).  Only when p.grad is None: with an existing gradient autograd would add the view to itself."""
+    if p is None or not p.is_leaf or p.grad is not None:
+        return None
+    slot = getattr(p, "_sfcvit_slot", None)
+    if slot is None:
+        return None
+    buf, off = slot
+    if getattr(p, "_sfcvit_claimed", -1) == buf.epoch:
+        return None                               # second use of a shared parameter in one backward: autograd must add
+    p._sfcvit_claimed = buf.epoch
+    return buf.flat_grad[off:off + p.numel()].view(p.shape)
+
+
+def _wgrad(dy2, x2, w=None):
+    """dW[out, in] = dY^T X  (contraction over rows; both operands k-major), into w's gradient slot if it has one."""
+    return ops.gemm(dy2, x2, a_kmajor=True, b_kmajor=True, out=_slot(w))
 
 
 class _SideStream:
@@ -72,8 +89,9 @@ import os as _os
 SIDE_STREAM_WGRAD = _os.environ.get("SFCVIT_SIDE_STREAM", "0") == "1"
 
 
-def _bgrad(dy2):
-    return ops.colsum(dy2).to(_BF16)
+def _bgrad(dy2, b=None):
+    out = _slot(b)
+    return ops.colsum(dy2, out=out) if out is not None else ops.colsum(dy2).to(_BF16)
 
 
 # ----------------------------------------------------------------------------
@@ -121,7 +139,7 @@ class _Linear(Function):
         elif ctx.act == ops.ACT_GELU:
             dy2 = ops.gelu_bwd(dy2, aux)
         dx = ops.gemm_dx(dy2, w).view(ctx.shape)
-        return dx, _wgrad(dy2, x2), (_bgrad(dy2) if ctx.has_bias else None), None
+        return dx, _wgrad(dy2, x2, w), (_bgrad(dy2) if ctx.has_bias else None), None
 
 
 def linear(x, weight, bias=None, act=ops.ACT_NONE):
@@ -181,9 +199,9 @@ class _Mixer(Function):
     def backward(ctx, dy):
         x2, mean, rstd, z, u, h, ln_w, w1, w2 = ctx.saved_tensors
         dy2 = _c(dy).view(-1, dy.shape[-1])
-        dw2, db2 = _wgrad(dy2, h), _bgrad(dy2)
+        dw2, db2 = _wgrad(dy2, h, w2), _bgrad(dy2)
         du = ops.gemm_dx(dy2, w2, aux_in=u, dact=ops.ACT_GELU)
-        dw1, db1 = _wgrad(du, z), _bgrad(du)
+        dw1, db1 = _wgrad(du, z, w1), _bgrad(du)
         dz = ops.gemm_dx(du, w1)
         dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w, dx_add=dy2)
         return dx.view(dy.shape), dg.to(_BF16), dbeta.to(_BF16), dw1, db1, dw2, db2, None
@@ -216,6 +234,7 @@ class _EncoderLayer(Function):
         ctx.save_for_backward(x2, qkv, o, lse, s1, mean1, rstd1, x1, h, s2, mean2, rstd2,
                               in_w, out_w, n1_w, w1, w2, n2_w)
         ctx.n_heads, ctx.shape, ctx.p, ctx.seeds = n_heads, (B, N, D), p, seeds
+        ctx.small = (in_b, out_b, n1_b, b1, b2, n2_b)      # parameters only needed for their gradient slots
         return y.view(B, N, D)
 
     @staticmethod
@@ -226,35 +245,42 @@ class _EncoderLayer(Function):
         p = ctx.p
         sa, s1_, sf, s2_ = ctx.seeds
         dy2 = _c(dy).view(B * N, D)
+        in_b, out_b, n1_b, b1, b2, n2_b = ctx.small
         ss = _SideStream(dy2.device) if SIDE_STREAM_WGRAD else None
-        wg = (lambda a_, b_: ss.run(lambda: _wgrad(a_, b_), a_, b_)) if ss else _wgrad
-        # LayerNorm backward also returns the column sums of the gradient it hands to the sub-layer:
-        # that is the bias gradient of linear2 / out_proj, for free in the same pass.
-        if p > 0:
-            ds2, dg2, dbt2, df, db2 = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w, drop_p=p, drop_seed=s2_, want_colsum=True)
-        else:
-            ds2, dg2, dbt2, db2 = ops.layernorm_bwd(dy2, s2, mean2, rstd2, n2_w, want_colsum=True)
-            df = ds2
-        dw2, db2 = wg(df, h), db2.to(_BF16)
+        wg = (lambda a_, b_, w_: ss.run(lambda: _wgrad(a_, b_, w_), a_, b_)) if ss else _wgrad
+
+        def ln_bwd(dyv, s, mean, rstd, g_w, g_b, prev_bias, seed):
+            """LayerNorm backward; also returns the column sums of the gradient it hands to the sub-layer = the bias
+            gradient of linear2 / out_proj, for free in the same pass.  Gradients go straight into their slots when
+            all three parameters have one."""
+            slots = (_slot(g_w), _slot(g_b), _slot(prev_bias))
+            go = slots if all(t is not None for t in slots) else None
+            if p > 0:
+                dsv, dg, dbt, dsub, dcol = ops.layernorm_bwd(dyv, s, mean, rstd, g_w, drop_p=p, drop_seed=seed,
+                                                             want_colsum=True, grad_out=go)
+            else:
+                dsv, dg, dbt, dcol = ops.layernorm_bwd(dyv, s, mean, rstd, g_w, want_colsum=True, grad_out=go)
+                dsub = dsv
+            if go is None:
+                dg, dbt, dcol = dg.to(_BF16), dbt.to(_BF16), dcol.to(_BF16)
+            return dsv, dg, dbt, dsub, dcol
+
+        ds2, dg2, dbt2, df, db2 = ln_bwd(dy2, s2, mean2, rstd2, n2_w, n2_b, b2, s2_)
+        dw2 = wg(df, h, w2)
         # h is stored after relu + dropout: (h > 0) is the joint mask, 1/(1-p) the dropout scale
         dh = ops.gemm_dx(df, w2, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p))
-        dw1, db1 = wg(dh, x1), _bgrad(dh)
+        dw1, db1 = wg(dh, x1, w1), _bgrad(dh, b1)
         dx1 = ops.gemm_dx(dh, w1, residual=ds2)
-        if p > 0:
-            ds1, dg1, dbt1, da, dbo = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w, drop_p=p, drop_seed=s1_, want_colsum=True)
-        else:
-            ds1, dg1, dbt1, dbo = ops.layernorm_bwd(dx1, s1, mean1, rstd1, n1_w, want_colsum=True)
-            da = ds1
+        ds1, dg1, dbt1, da, dbo = ln_bwd(dx1, s1, mean1, rstd1, n1_w, n1_b, out_b, s1_)
         o2 = o.view(B * N, D)
-        dwo, dbo = wg(da, o2), dbo.to(_BF16)
+        dwo = wg(da, o2, out_w)
         do = ops.gemm_dx(da, out_w)
         dqkv = ops.attention_bwd(qkv.view(B, N, 3 * D), o, lse, do.view(B, N, D), ctx.n_heads, p, sa).view(B * N, 3 * D)
-        dwi, dbi = wg(dqkv, x2), _bgrad(dqkv)
+        dwi, dbi = wg(dqkv, x2, in_w), _bgrad(dqkv, in_b)
         dx = ops.gemm_dx(dqkv, in_w, residual=ds1)
         if ss:
             ss.join(dw2, dw1, dwo, dwi)
-        return (dx.view(B, N, D), dwi, dbi, dwo, dbo, dg1.to(_BF16), dbt1.to(_BF16), dw1, db1, dw2, db2,
-                dg2.to(_BF16), dbt2.to(_BF16), None, None, None, None)
+        return (dx.view(B, N, D), dwi, dbi, dwo, dbo, dg1, dbt1, dw1, db1, dw2, db2, dg2, dbt2, None, None, None, None)
 
 
 def encoder_layer(x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps=1e-5,

@@ -96,13 +96,15 @@ def auto_splitk(M, N, K):
     15 % against 1008 = 1.97), each k-range keeps >= 896 deep, and -- for outputs under 64 tiles,
     where sfcvit_gemm gives every XCD its own k-ranges -- is a multiple of 8."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 256 or K < 2048:
+    if K < 2048:
         return 1
-    if M % 256 == 0 and N % 256 == 0 and K % 128 == 0:
+    if M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and (M // 256) * (N // 256) <= 128:
         # weight-gradient form of the 8-phase kernel: one workgroup per CU, tiles256 x splits <= 256
         s = min(64, 256 // ((M // 256) * (N // 256)))
         if s >= 2 and K // s >= 512:
             return s
+    if tiles >= 256:
+        return 1
     step = 8 if tiles < 64 else 1
     best, best_eff = 1, tiles / 512.0 if tiles < 512 else 1.0
     for s in range(max(2, step), 65, step):
@@ -197,12 +199,17 @@ def gemm_dx(dy, w, **kw):
     return gemm(dy, w, b_kmajor=True, **kw)
 
 
-def colsum(x):
+def colsum(x, out=None):
+    """Column sums [N]: fp32 (new tensor), or written as bf16 into `out` (e.g. a view of a flat gradient buffer)."""
     _rows2d(x, _BF16, "colsum x")
-    out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+    elif out.dtype != _BF16 or out.numel() != x.shape[1] or not out.is_contiguous():
+        raise ValueError("colsum out: contiguous bf16 [N] expected")
     nbytes = lib.sfcvit_colsum_workspace(x.shape[0], x.shape[1])
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-    check(lib.sfcvit_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(out), _p(ws), nbytes, _stream()), "sfcvit_colsum")
+    check(lib.sfcvit_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(out), int(out.dtype == _BF16), _p(ws), nbytes,
+                            _stream()), "sfcvit_colsum")
     return out
 
 
@@ -220,22 +227,32 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0, want_colsum=False):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0, want_colsum=False, grad_out=None):
     """-> dx, dgamma, dbeta [, dx_drop when drop_p > 0] [, colsum of the outgoing gradient (dx_drop if
-    drop_p > 0 else dx) when want_colsum]."""
+    drop_p > 0 else dx) when want_colsum].  dgamma / dbeta / colsum are fp32 [D], or -- with
+    grad_out = (dgamma, dbeta, colsum-or-None) bf16 [D] tensors, e.g. views of a flat gradient buffer (None entries
+    are allocated) -- written as bf16 in place."""
     _need(dy, _BF16, "layernorm dy", 2)
     _need(x, _BF16, "layernorm x", 2)
     M, D = x.shape
     dx = torch.empty_like(x)
     dx_drop = torch.empty_like(x) if drop_p > 0 else None
-    dg = torch.empty(D, device=x.device, dtype=torch.float32)
-    db = torch.empty(D, device=x.device, dtype=torch.float32)
+    gdt = torch.float32 if grad_out is None else _BF16
+    given = (None, None, None) if grad_out is None else grad_out
+    for t in given:
+        if t is not None and (t.dtype != _BF16 or t.numel() != D or not t.is_contiguous()):
+            raise ValueError("layernorm_bwd grad_out: contiguous bf16 [D] tensors expected")
+    dg = given[0] if given[0] is not None else torch.empty(D, device=x.device, dtype=gdt)
+    db = given[1] if given[1] is not None else torch.empty(D, device=x.device, dtype=gdt)
     ws = torch.empty(lib.sfcvit_layernorm_bwd_ws(M, D), device=x.device, dtype=torch.uint8)
     if dx_add is not None:
         _need(dx_add, _BF16, "layernorm dx_add", 2)
-    dcol = torch.empty(D, device=x.device, dtype=torch.float32) if want_colsum else None
+    dcol = None
+    if want_colsum:
+        dcol = given[2] if given[2] is not None else torch.empty(D, device=x.device, dtype=gdt)
     check(lib.sfcvit_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_add), _p(dx), _p(dx_drop),
-                                        drop_p, drop_seed, _p(dg), _p(db), _p(dcol), M, D, _p(ws), _stream()),
+                                        drop_p, drop_seed, _p(dg), _p(db), _p(dcol), int(gdt == _BF16), M, D, _p(ws),
+                                        _stream()),
           "sfcvit_layernorm_bwd")
     out = (dx, dg, db) + ((dx_drop,) if drop_p > 0 else ()) + ((dcol,) if want_colsum else ())
     return out

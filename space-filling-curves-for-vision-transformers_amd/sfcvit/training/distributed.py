@@ -73,6 +73,7 @@ class GradReducer:
     def _on_grad(self, p):
         if self._pending is None:
             return
+        self.opt.adopt(p)                        # the bucket is a slice of the flat buffer: the gradient must be in it
         b = self._param_bucket[id(p)]
         self._pending[b] -= 1
         if self._pending[b] == 0:

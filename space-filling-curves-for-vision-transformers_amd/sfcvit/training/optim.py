@@ -27,6 +27,7 @@ class FlatGradBuffer:
         self.flat_param = self.flat_grad = None
         self.active = None                      # parameters that receive gradients, flat order
         self.offsets = None
+        self.epoch = 0                          # bumped by zero_grad: one in-place gradient write per parameter and step
 
     def _check(self, p):
         pass
@@ -55,6 +56,7 @@ class FlatGradBuffer:
                 self.flat_grad[o:o + k].copy_(p.grad.reshape(-1))
             p.data = self.flat_param[o:o + k].view(p.shape)
             p.grad = self.flat_grad[o:o + k].view(p.shape)
+            p._sfcvit_slot = (self, o)           # functional._slot: kernels write this parameter's gradient in place
         self._built()
 
     def _built(self):
@@ -64,12 +66,35 @@ class FlatGradBuffer:
         """[(offset, numel, parameter)] in flat order (used by the data-parallel reducer)."""
         return [(o, p.numel(), p) for p, o in zip(self.active, self.offsets)]
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=True):
+        """Zero the flat gradient buffer.  With set_to_none (default, as torch.optim) every p.grad is dropped too:
+        backward then writes gradients straight into the buffer and autograd adopts those views (functional._slot);
+        gradients that arrive as separate tensors are moved in by `adopt` before they are used."""
         if self.flat_grad is None:
             for p in self.params:
                 p.grad = None
-        else:
-            self.flat_grad.zero_()               # p.grad stay views of the flat buffer
+            return
+        self.flat_grad.zero_()
+        self.epoch += 1
+        if set_to_none:
+            for p in self.active:
+                p.grad = None
+
+    def adopt(self, p, o=None):
+        """Make p.grad the view of the flat buffer again (copying a gradient that was produced elsewhere)."""
+        if o is None:
+            o = p._sfcvit_slot[1]
+        view = self.flat_grad[o:o + p.numel()].view(p.shape)
+        g = p.grad
+        if g is None:
+            p.grad = view                        # no gradient this step: the zeroed slot
+        elif g.data_ptr() != view.data_ptr():
+            view.copy_(g)
+            p.grad = view
+
+    def adopt_all(self):
+        for p, o in zip(self.active, self.offsets):
+            self.adopt(p, o)
 
 
 class FusedAdamW(FlatGradBuffer):
@@ -109,6 +134,8 @@ class FusedAdamW(FlatGradBuffer):
     def step(self):
         if self.flat_grad is None:
             self._build()
+        else:
+            self.adopt_all()
         self.step_count += 1
         sumsq = None
         if self.max_grad_norm is not None:
