@@ -2,6 +2,7 @@
 // (bias gradients), GELU, soft-target cross-entropy, sum of squares and the fused
 // clip + AdamW step.  One 64-lane wave owns one row; every global access is a
 // 16-byte vector (8 bf16 or 4 fp32) and reductions are wave butterflies.
+#include <cstdlib>
 #include "common_host.h"
 #include "device_common.h"
 
@@ -104,8 +105,30 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
 #pragma unroll
         for (int j = 0; j < 8; j++) dg[i][j] = db[i][j] = dc[i][j] = 0.f;
     }
-    for (int row = blockIdx.x * WAVES + wave; row < M; row += gridDim.x * WAVES) {
-        const float mu = mean[row], rs = rstd[row];
+    // Rows are software-pipelined: the loads of this wave's next row are issued before the current row is reduced
+    // (a row is load -> two wave reductions -> store, and only 8 waves per CU are resident: without the prefetch
+    // the kernel sat at 2.7-3.3 TB/s, latency- not bandwidth-bound).
+    const int stride = gridDim.x * WAVES;
+    u32x4 xr[VPL], dr[VPL], ar[VPL], xn[VPL], dn[VPL], an[VPL];
+    float mu = 0.f, rs = 0.f, mun = 0.f, rsn = 0.f;
+    auto load_row = [&](int row, u32x4 (&xq)[VPL], u32x4 (&dq)[VPL], u32x4 (&aq)[VPL], float &m, float &r) __attribute__((always_inline)) {
+        m = mean[row];
+        r = rstd[row];
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                xq[i] = *reinterpret_cast<const u32x4 *>(x + size_t(row) * D + c * 8);
+                dq[i] = *reinterpret_cast<const u32x4 *>(dy + size_t(row) * D + c * 8);
+                if (dx_add) aq[i] = *reinterpret_cast<const u32x4 *>(dx_add + size_t(row) * D + c * 8);
+            }
+        }
+    };
+    int row = blockIdx.x * WAVES + wave;
+    if (row < M) load_row(row, xr, dr, ar, mu, rs);
+    for (; row < M; row += stride) {
+        const bool more = row + stride < M;
+        if (more) load_row(row + stride, xn, dn, an, mun, rsn);
         float xh[VPL][8], gy[VPL][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -113,8 +136,8 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
             const int c = lane + 64 * i;
             if (c < nvec) {
                 float xv[8], dv[8];
-                unpack8(*reinterpret_cast<const u32x4 *>(x + size_t(row) * D + c * 8), xv);
-                unpack8(*reinterpret_cast<const u32x4 *>(dy + size_t(row) * D + c * 8), dv);
+                unpack8(xr[i], xv);
+                unpack8(dr[i], dv);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     xh[i][j] = (xv[j] - mu) * rs;
@@ -136,7 +159,7 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                 for (int j = 0; j < 8; j++) o[j] = rs * (gy[i][j] - c1 - xh[i][j] * c2);
                 if (dx_add) {
                     float a[8];
-                    unpack8(*reinterpret_cast<const u32x4 *>(dx_add + size_t(row) * D + c * 8), a);
+                    unpack8(ar[i], a);
 #pragma unroll
                     for (int j = 0; j < 8; j++) o[j] += a[j];
                 }
@@ -159,6 +182,12 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                     for (int j = 0; j < 8; j++) dc[i][j] += o[j];
                 }
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < VPL; i++) { xr[i] = xn[i]; dr[i] = dn[i]; ar[i] = an[i]; }
+            mu = mun;
+            rs = rsn;
         }
     }
 #pragma unroll
@@ -212,7 +241,13 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float *__restrict__ p
 
 int ln_bwd_blocks(int M) {
     const int want = (M + WAVES - 1) / WAVES;
-    return want < 512 ? want : 512;
+    static int cap = 0;
+    if (!cap) {
+        const char *e = getenv("SFCVIT_LN_BLOCKS");       // tuning knob (tools/bench_rowwise.py); default below
+        cap = e ? atoi(e) : 512;
+        if (cap < 1) cap = 512;
+    }
+    return want < cap ? want : cap;
 }
 
 // ---------------------------------------------------------------------------

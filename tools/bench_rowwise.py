@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the row-wise kernels at the ViT-B step's shapes (M = 50176, D = 768): LayerNorm fwd / bwd,
+column sums.  Prints us per launch and the achieved HBM rate on the algorithmic bytes.
+SFCVIT_LN_BLOCKS=<n> changes the LayerNorm-backward grid (one process per setting)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "space-filling-curves-for-vision-transformers_amd"))
+import torch  # noqa: E402
+from sfcvit import ops  # noqa: E402
+
+M, D = 50176, 768
+g = torch.Generator(device="cuda").manual_seed(0)
+x = torch.randn(M, D, device="cuda", generator=g).bfloat16()
+dy = torch.randn(M, D, device="cuda", generator=g).bfloat16()
+w = torch.randn(D, device="cuda", generator=g).bfloat16()
+b = torch.randn(D, device="cuda", generator=g).bfloat16()
+big = torch.randn(M, 3072, device="cuda", generator=g).bfloat16()
+y, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-5)
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+cases = [("ln_fwd", lambda: ops.layernorm_fwd(x, w, b, 1e-5), 2 * M * D * 2),
+         ("ln_bwd", lambda: ops.layernorm_bwd(dy, x, mean, rstd, w), 3 * M * D * 2),
+         ("ln_bwd + dropout out + colsum", lambda: ops.layernorm_bwd(dy, x, mean, rstd, w, drop_p=0.1, drop_seed=5, want_colsum=True), 4 * M * D * 2),
+         ("colsum [M,768]", lambda: ops.colsum(x), M * D * 2),
+         ("colsum [M,3072]", lambda: ops.colsum(big), M * 3072 * 2)]
+print("SFCVIT_LN_BLOCKS =", os.environ.get("SFCVIT_LN_BLOCKS", "(default)"))
+for name, fn, nbytes in cases:
+    us = timeit(fn)
+    print(f"{name:34s} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s")
