@@ -1,6 +1,7 @@
 // Whole-sequence attention kernels for gfx950 (head dim 64, N <= 256: every ViT at 16x16-pixel
 // tokens up to 256x256 images).  One workgroup per (batch, head): K and V (forward, dQ) or Q and
-// dO (dK/dV) are staged into LDS ONCE for the whole sequence (2 x 28 KiB at N = 196), then every
+// dO (dK/dV) are staged into LDS ONCE for the whole sequence (2 x 26 KiB at N = 196: the forward and dQ kernels
+// pad the sequence to 16, not 32, keys so that THREE workgroups fit a CU's 160 KiB), then every
 // wave walks its 16-row fragments with no barrier in the loop and no online-softmax rescale
 // (a whole score row, <= 16 fragments, lives in registers).  The tiled kernels of attention.hip
 // re-staged K/V for every 64 queries and synchronised twice per 64 keys; they remain the path
@@ -25,7 +26,7 @@ typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 template <bool VT>
 __device__ __forceinline__ void dma_seq(char *img, const uint16_t *__restrict__ src, int ld, int N, int npad, int tid) {
-    for (int p = tid; p < npad * 8; p += THREADS) {     // npad % 32 == 0: every thread runs the same trip count
+    for (int p = tid; p < npad * 8; p += THREADS) {     // npad % 32 == 16: the last trip is half a workgroup
         const int row = p >> 3, cs = p & 7;
         const int c = VT ? ((((cs >> 1) ^ ((row >> 1) & 3)) << 1) | (cs & 1)) : (cs ^ ((row >> 1) & 7));
         const uint16_t *g = src + size_t(min(row, N - 1)) * ld + c * 8;
@@ -33,10 +34,19 @@ __device__ __forceinline__ void dma_seq(char *img, const uint16_t *__restrict__ 
     }
 }
 
+// 16 rows x 16 cols transposed fragment for the 16-deep MFMA (the odd last 16 keys of a sequence padded to 16)
+__device__ __forceinline__ bf16x4 tr_frag16_at(const char *img, int r_lo, int lane_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFCVIT_LDS bf16x4 *)(img + r_lo * 128 + lane_off));
+}
+__device__ __forceinline__ bf16x4 pack_frag4(const f32x4 &a) {
+    const u32x2 w = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+    return __builtin_bit_cast(bf16x4, w);
+}
+
 constexpr int WAVES = THREADS / 64;
 constexpr int MAXOWN = MAXF / WAVES;   // fragments a wave owns at most (4)
 
-__global__ __launch_bounds__(THREADS, 2) void attn_seq_fwd_kernel(const sfcvit_attn_args a, int npad) {
+__global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_attn_args a, int npad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *kimg = smem, *vimg = smem + npad * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_fwd_kernel(const sfcvit_a
     const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
     const uint16_t *qp = base, *kp = base + D, *vp = base + 2 * D;
     uint16_t *out = static_cast<uint16_t *>(a.out) + size_t(b) * N * D + h * HD;
-    const int nf = (N + 15) >> 4, nc = npad >> 5;
+    const int nf = (N + 15) >> 4, nc = npad >> 5;        // npad = 16 nf; nc full 32-key chunks (+ a 16-key tail if nf is odd)
     // This wave's query fragments, fetched before the K/V staging so that their HBM latency is
     // hidden behind it (fragment index = wave + 4*o).
     bf16x8 qfr[MAXOWN][2];
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_fwd_kernel(const sfcvit_a
 #pragma unroll
         for (int kf = 0; kf < MAXF; kf++) {
             s[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kf < 2 * nc) {
+            if (kf < nf) {
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++)
                     s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(kimg, 16 * kf, lo.k[kk]), qfr[o][kk], s[kf], 0, 0, 0);
@@ -81,8 +91,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_fwd_kernel(const sfcvit_a
         float mx = -INFINITY;
 #pragma unroll
         for (int kf = 0; kf < MAXF; kf++)
-            if (kf < 2 * nc) {
-                if (16 * kf + 16 > N) {                  // only the boundary / padding fragments need the key mask
+            if (kf < nf) {
+                if (16 * kf + 16 > N) {                  // only the boundary fragment needs the key mask
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         if (16 * kf + 4 * (lane >> 4) + r >= N) s[kf][r] = -INFINITY;
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_fwd_kernel(const sfcvit_a
         const uint32_t drk = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
 #pragma unroll
         for (int kf = 0; kf < MAXF; kf++)
-            if (kf < 2 * nc) {
+            if (kf < nf) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     s[kf][r] = fast_exp2(s[kf][r] * c2 - mc);
@@ -121,6 +131,16 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_fwd_kernel(const sfcvit_a
                 for (int hf = 0; hf < 4; hf++)
                     acc[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_at(vimg, 32 * c, lo.tv[hf]), pf, acc[hf], 0, 0, 0);
             }
+        if (nf & 1) {                                    // the last 16 keys (wave-uniform; s[] only by constant index)
+#pragma unroll
+            for (int kf = 0; kf < MAXF; kf += 2)
+                if (kf == nf - 1) {
+                    const bf16x4 pf = pack_frag4(s[kf]);
+#pragma unroll
+                    for (int hf = 0; hf < 4; hf++)
+                        acc[hf] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tr_frag16_at(vimg, 16 * kf, lo.tv[hf]), pf, acc[hf], 0, 0, 0);
+                }
+        }
         mfma_fence();
         store_rows(out, D, q, q < N, acc, 1.f / l, lane);
         if (q < N && lane < 16) a.lse[(size_t(b) * a.H + h) * N + q] = mx * a.scale + __logf(l);
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_bwd_kv_kernel(const sfcvi
 }
 
 // dQ: waves own 16-query fragments; K and V of the whole sequence are in LDS.
-__global__ __launch_bounds__(THREADS, 2) void attn_seq_bwd_q_kernel(const sfcvit_attn_args a, int npad) {
+__global__ __launch_bounds__(THREADS, 3) void attn_seq_bwd_q_kernel(const sfcvit_attn_args a, int npad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *kimg = smem, *vimg = smem + npad * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -259,31 +279,37 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_bwd_q_kernel(const sfcvit
         f32x4 dq[4];
 #pragma unroll
         for (int hf = 0; hf < 4; hf++) dq[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < nc; c++) {
-            f32x4 ds[2];
+        // dS of one 16-key fragment: exp2(s c2 - lse) (dP keep - delta) scale, keys >= N zeroed
+        auto ds_frag = [&](int kfi) __attribute__((always_inline)) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f}, ds;
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int kfi = 2 * c + t;
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 2; kk++) {
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(kimg, 16 * kfi, lo.k[kk]), qfr[kk], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(vimg, 16 * kfi, lo.k[kk]), dof[kk], dp, 0, 0, 0);
-                }
-                float keep[4] = {1.f, 1.f, 1.f, 1.f};
-                if (drop) drop_keep4(drk, 16 * kfi + 4 * (lane >> 4), dth, dsc, keep);
-#pragma unroll
-                for (int r = 0; r < 4; r++) ds[t][r] = fast_exp2(s[r] * c2 - lse_q) * (dp[r] * keep[r] - del_q) * scale;
-                if (16 * kfi + 16 > N) {                 // boundary / padding fragment: keys >= N carry no gradient
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (16 * kfi + 4 * (lane >> 4) + r >= N) ds[t][r] = 0.f;
-                }
+            for (int kk = 0; kk < 2; kk++) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(kimg, 16 * kfi, lo.k[kk]), qfr[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(vimg, 16 * kfi, lo.k[kk]), dof[kk], dp, 0, 0, 0);
             }
-            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+            float keep[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop) drop_keep4(drk, 16 * kfi + 4 * (lane >> 4), dth, dsc, keep);
+#pragma unroll
+            for (int r = 0; r < 4; r++) ds[r] = fast_exp2(s[r] * c2 - lse_q) * (dp[r] * keep[r] - del_q) * scale;
+            if (16 * kfi + 16 > N) {                     // boundary fragment: keys >= N carry no gradient
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (16 * kfi + 4 * (lane >> 4) + r >= N) ds[r] = 0.f;
+            }
+            return ds;
+        };
+        for (int c = 0; c < nc; c++) {
+            const f32x4 d0 = ds_frag(2 * c), d1 = ds_frag(2 * c + 1);
+            const bf16x8 dsf = pack_frag(d0, d1);
 #pragma unroll
             for (int hf = 0; hf < 4; hf++)
                 dq[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_at(kimg, 32 * c, lo.t[hf]), dsf, dq[hf], 0, 0, 0);
+        }
+        if (nf & 1) {                                    // the last 16 keys
+            const bf16x4 dsf = pack_frag4(ds_frag(nf - 1));
+#pragma unroll
+            for (int hf = 0; hf < 4; hf++)
+                dq[hf] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tr_frag16_at(kimg, 16 * (nf - 1), lo.t[hf]), dsf, dq[hf], 0, 0, 0);
         }
         mfma_fence();
         store_rows(dbase, ld, q, q < N, dq, 1.f, lane);
@@ -309,7 +335,7 @@ int set_lds_limit() {
 int attn_seq_fwd(const sfcvit_attn_args &a, hipStream_t s) {
     if (a.N > SEQ_MAX_N) return -1;
     if (int rc = set_lds_limit()) return rc;
-    const int npad = (a.N + 31) / 32 * 32;
+    const int npad = (a.N + 15) / 16 * 16;
     hipLaunchKernelGGL(attn_seq_fwd_kernel, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128), s, a, npad);
     return check_launch("attention_seq_fwd");
 }
@@ -320,7 +346,8 @@ int attn_seq_bwd(const sfcvit_attn_args &a, hipStream_t s) {
     const int npad = (a.N + 31) / 32 * 32;
     hipLaunchKernelGGL(attn_seq_bwd_kv_kernel, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128 + 3 * npad * 4), s, a, npad);
     if (int rc = check_launch("attention_seq_bwd kv")) return rc;
-    hipLaunchKernelGGL(attn_seq_bwd_q_kernel, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128), s, a, npad);
+    const int npad16 = (a.N + 15) / 16 * 16;
+    hipLaunchKernelGGL(attn_seq_bwd_q_kernel, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad16 * 128), s, a, npad16);
     return check_launch("attention_seq_bwd q");
 }
 
