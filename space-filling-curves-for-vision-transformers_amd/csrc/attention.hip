@@ -122,18 +122,20 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(const sfcvit_attn_arg
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void attn_delta_kernel(const uint16_t *__restrict__ dout,
                                                              const uint16_t *__restrict__ out, float *__restrict__ delta,
-                                                             int B, int N, int H) {
-    // one 8-lane group per (b, q, h): 8 lanes x 8 elements = 64
+                                                             int B, int N, int H, int hd) {
+    // one 8-lane group per (b, q, h): 8 lanes x 8 elements per 64 columns of the head
     const int64_t grp = (int64_t(blockIdx.x) * THREADS + threadIdx.x) >> 3;
     const int sub = threadIdx.x & 7;
     const int64_t total = int64_t(B) * N * H;
     float s = 0.f;
     if (grp < total) {
-        const size_t off = size_t(grp) * HD + sub * 8;   // [B, N, H, hd] is contiguous
-        const u32x4 x = *reinterpret_cast<const u32x4 *>(dout + off), y = *reinterpret_cast<const u32x4 *>(out + off);
+        for (int c0 = 0; c0 < hd; c0 += 64) {
+            const size_t off = size_t(grp) * hd + c0 + sub * 8;   // [B, N, H, hd] is contiguous
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(dout + off), y = *reinterpret_cast<const u32x4 *>(out + off);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            s += bf2f(uint16_t(x[i])) * bf2f(uint16_t(y[i])) + bf2f(uint16_t(x[i] >> 16)) * bf2f(uint16_t(y[i] >> 16));
+            for (int i = 0; i < 4; i++)
+                s += bf2f(uint16_t(x[i])) * bf2f(uint16_t(y[i])) + bf2f(uint16_t(x[i] >> 16)) * bf2f(uint16_t(y[i] >> 16));
+        }
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
@@ -299,7 +301,8 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(const sfcvit_attn_a
 int check_args(const sfcvit_attn_args *a, const char *what, bool bwd) {
     if (!a || !a->qkv || !a->out || !a->lse) return fail(SFCVIT_EINVAL, "%s: null pointer", what);
     if (bwd && (!a->dout || !a->dqkv || !a->delta)) return fail(SFCVIT_EINVAL, "%s: null pointer", what);
-    if (a->hd != HD) return fail(SFCVIT_EINVAL, "%s: head dim %d not supported (this build: 64)", what, a->hd);
+    if (a->hd != 64 && a->hd != 128 && a->hd != 192 && a->hd != 256)
+        return fail(SFCVIT_EINVAL, "%s: head dim %d not supported (64, 128, 192, 256)", what, a->hd);
     if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return fail(SFCVIT_EINVAL, "%s: dropout_p=%g out of [0, 1)", what, a->dropout_p);
     if (a->B <= 0 || a->N <= 0 || a->H <= 0 || a->B > 65535 || a->H > 65535)
         return fail(SFCVIT_EINVAL, "%s: B=%d N=%d H=%d", what, a->B, a->N, a->H);
@@ -313,6 +316,9 @@ int check_args(const sfcvit_attn_args *a, const char *what, bool bwd) {
 // attention_seq.hip: whole-sequence kernels; return -1 when N is too long for them.
 int attn_seq_fwd(const sfcvit_attn_args &a, hipStream_t s);
 int attn_seq_bwd(const sfcvit_attn_args &a, hipStream_t s);
+// attention_wide.hip: head dims 128 / 192 / 256; return -1 for head dim 64.
+int attn_wide_fwd(const sfcvit_attn_args &a, hipStream_t s);
+int attn_wide_bwd(const sfcvit_attn_args &a, hipStream_t s);
 
 }  // namespace sfcvit
 
@@ -320,6 +326,7 @@ using namespace sfcvit;
 
 extern "C" int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream) {
     if (int rc = check_args(a, "attention_fwd", false)) return rc;
+    if (int rc = attn_wide_fwd(*a, static_cast<hipStream_t>(stream)); rc >= 0) return rc;
     if (int rc = attn_seq_fwd(*a, static_cast<hipStream_t>(stream)); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a);
@@ -331,8 +338,9 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t groups = int64_t(a->B) * a->N * a->H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(unsigned((groups * 8 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s,
-                       static_cast<const uint16_t *>(a->dout), static_cast<const uint16_t *>(a->out), a->delta, a->B, a->N, a->H);
+                       static_cast<const uint16_t *>(a->dout), static_cast<const uint16_t *>(a->out), a->delta, a->B, a->N, a->H, a->hd);
     if (int rc = check_launch("attention_bwd delta")) return rc;
+    if (int rc = attn_wide_bwd(*a, s); rc >= 0) return rc;
     if (int rc = attn_seq_bwd(*a, s); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
     hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(THREADS), 0, s, *a);

@@ -65,8 +65,7 @@ def main():
     ap.add_argument("--levels", type=int, nargs="+", default=[16, 4, 1])
     ap.add_argument("--embed-dim", type=int, default=256)
     ap.add_argument("--depth", type=int, default=8)             # main.py:276-282
-    ap.add_argument("--heads", type=int, default=12, help="head dim must be 64 for the HIP attention kernels "
-                    "(the reference's 768/4 = 192 is not supported yet)")
+    ap.add_argument("--heads", type=int, default=4)             # head dim 768 / 4 = 192 (attention_wide.hip)
     ap.add_argument("--mlp-dim", type=int, default=512)
     ap.add_argument("--classes", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=512)      # main.py:228

@@ -392,3 +392,44 @@ def test_gemm_weight_gradient_8phase_kernel(ops, M, N, K, splitk):
     want = torch.zeros(M, N, device="cuda")
     want.index_add_(0, torch.arange(M, device="cuda"), b.float()[idx])
     assert torch.equal(ops.gemm(a1, b, a_kmajor=True, b_kmajor=True, splitk=splitk).float(), want.bfloat16().float())
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(2, 64, 4, 192), (2, 196, 2, 128), (1, 100, 1, 256), (3, 180, 1, 192), (2, 5, 2, 128)])
+def test_attention_wide_heads(ops, B, N, H, hd):
+    """Head dims 128 / 192 / 256 (the reference's own script uses 768 / 4 = 192, main.py:276-282): forward, lse and the
+    packed dqkv against fp32 math; run-to-run identical."""
+    g = torch.Generator(device="cuda").manual_seed(15)
+    qkv = bf(torch.randn(B, N, 3 * H * hd, device="cuda", generator=g))
+    dout = bf(torch.randn(B, N, H * hd, device="cuda", generator=g))
+    qf = qkv.float().requires_grad_(True)
+    ref, lse_ref = attn_ref(qf, H)
+    ref.backward(dout.float())
+    out, lse = ops.attention_fwd(qkv, H)
+    close(out, ref.detach())
+    assert torch.allclose(lse, lse_ref.detach(), atol=2e-2, rtol=1e-2)
+    dqkv = ops.attention_bwd(qkv, out, lse, dout, H)
+    close(dqkv, qf.grad, rel=1.0 / 64, abs_scale=1.0 / 32)
+    o2, l2 = ops.attention_fwd(qkv, H)
+    assert torch.equal(o2, out) and torch.equal(l2, lse) and torch.equal(ops.attention_bwd(qkv, out, lse, dout, H), dqkv)
+
+
+def test_attention_wide_heads_dropout_and_limits(ops):
+    B, N, H, hd, p, seed = 2, 64, 4, 192, 0.1, 99
+    D = H * hd
+    g = torch.Generator(device="cuda").manual_seed(16)
+    qkv = bf(torch.randn(B, N, 3 * D, device="cuda", generator=g))
+    dout = bf(torch.randn(B, N, D, device="cuda", generator=g))
+    mask = ops.dropout_mask(B * H * N, N, p, seed).float().view(B, H, N, N)
+    qf = qkv.float().requires_grad_(True)
+    q, k, v = qf.split(D, dim=-1)
+    sp = lambda t: t.reshape(B, N, H, hd).transpose(1, 2)
+    s = (sp(q) @ sp(k).transpose(-1, -2)) / math.sqrt(hd)
+    ref = ((torch.softmax(s, -1) * mask) @ sp(v)).transpose(1, 2).reshape(B, N, D)
+    ref.backward(dout.float())
+    out, lse = ops.attention_fwd(qkv, H, p, seed)
+    close(out, ref.detach())
+    close(ops.attention_bwd(qkv, out, lse, dout, H, p, seed), qf.grad, rel=1 / 48, abs_scale=1 / 24)
+    with pytest.raises(Exception, match="head dim"):            # 96 is not a multiple of 64
+        ops.attention_fwd(bf(torch.randn(1, 16, 3 * 96, device="cuda")), 1)
+    with pytest.raises(Exception, match="LDS"):                 # 576 tokens x head dim 128 do not fit one CU's LDS
+        ops.attention_fwd(bf(torch.randn(1, 576, 3 * 128, device="cuda")), 1)
