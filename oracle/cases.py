@@ -72,3 +72,10 @@ TOKENIZER_CASES = {
 RANDPERM_SEED = 1234       # torch.manual_seed before RandomEmbedding.forward (it draws torch.randperm on the CPU)
 SPIRAL_N = (1, 2, 3, 4, 7, 14, 32)
 HILBERT_T_N = (1, 2, 4, 8, 16, 32)
+
+# name -> (class, kwargs, batch): src/models/altvit.py
+ALTVIT_CASES = {
+    "hilbertvit32": ("HilbertViT", dict(image_size=32, patch_size=4, num_classes=10, dim=128, depth=2, heads=2, mlp_dim=256), 3),
+    "simplevit32": ("SimpleViT", dict(image_size=32, patch_size=8, num_classes=7, dim=64, depth=1, heads=1, mlp_dim=128), 2),
+    "hilbertvit64_p16": ("HilbertViT", dict(image_size=64, patch_size=16, num_classes=10, dim=192, depth=1, heads=3, mlp_dim=384), 2),
+}

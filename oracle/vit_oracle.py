@@ -417,3 +417,79 @@ def train_step(x, targets, sd, cfg, opt, clip=1.0):
     torch.nn.utils.clip_grad_norm_(params, clip, foreach=False)
     opt.step()
     return loss.detach(), logits.detach()
+
+
+# ----------------------------------------------------------------------------
+# altvit (src/models/altvit.py): SimpleViT / HilbertViT
+# ----------------------------------------------------------------------------
+def altvit_patches(x, p):
+    """'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (altvit.py:88-90,176-177)."""
+    b, c, h, w = x.shape
+    return x.reshape(b, c, h // p, p, w // p, p).permute(0, 2, 4, 3, 5, 1).reshape(b, (h // p) * (w // p), p * p * c)
+
+
+def altvit_pos_embedding(kind, grid, dim, T=4, h_param=3.0):
+    """SimpleViT: posemb_sincos_1d (altvit.py:16-41); HilbertViT: the Hilbert-index encoding (altvit.py:229-251)."""
+    n = grid * grid
+    if kind == "simple":
+        pe = torch.zeros(n, dim)
+        position = torch.arange(n, dtype=torch.float32).unsqueeze(1)
+        div = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * (-math.log(10000.0) / dim))
+        pe[:, 0::2] = torch.sin(position * div)
+        pe[:, 1::2] = torch.cos(position * div)
+        return pe
+    pos = torch.from_numpy(_curves.flat_table("hilbert", grid)).to(torch.float32).unsqueeze(1)
+    i_ar = torch.arange(dim // 2, dtype=torch.float32).unsqueeze(0)
+    two_pi = 2 * math.pi
+    arg = (2.0 * i_ar * grid ** 2 * pos * two_pi) / (T * n * dim) + h_param * (2.0 * i_ar * pos * two_pi) / dim
+    return torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
+
+
+def altvit_forward(x, sd, kind, patch, heads, depth):
+    """kind 'simple' | 'hilbert' (altvit.py:196-205, 260-268); pre-norm blocks altvit.py:116-160."""
+    pre = "to_patch_embedding."
+    names = ("1.", "2.", "3.") if kind == "simple" else ("layernorm1.", "linear.", "layernorm2.")
+    t = altvit_patches(x, patch)
+    if kind == "hilbert":
+        grid = x.shape[-1] // patch
+        t = t[:, torch.from_numpy(_curves.flat_table("hilbert", grid))]      # private recursion == src/curves order (2^k grids)
+    t = layer_norm(t, sd[pre + names[0] + "weight"], sd[pre + names[0] + "bias"])
+    t = t @ sd[pre + names[1] + "weight"].t() + sd[pre + names[1] + "bias"]
+    t = layer_norm(t, sd[pre + names[2] + "weight"], sd[pre + names[2] + "bias"])
+    t = t + sd["pos_embedding"]
+    B, N, D = t.shape
+    for i in range(depth):
+        a, f = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1.net."
+        z = layer_norm(t, sd[a + "norm.weight"], sd[a + "norm.bias"])
+        qkv = z @ sd[a + "to_qkv.weight"].t()
+        inner = qkv.shape[-1] // 3
+        hd = inner // heads
+        q, k, v = (u.reshape(B, N, heads, hd).transpose(1, 2) for u in qkv.split(inner, dim=-1))
+        p = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1)
+        o = (p @ v).transpose(1, 2).reshape(B, N, inner)
+        t = o @ sd[a + "to_out.weight"].t() + t
+        z = layer_norm(t, sd[f + "0.weight"], sd[f + "0.bias"])
+        z = gelu_erf(z @ sd[f + "1.weight"].t() + sd[f + "1.bias"])
+        t = z @ sd[f + "3.weight"].t() + sd[f + "3.bias"] + t
+    t = layer_norm(t, sd["transformer.norm.weight"], sd["transformer.norm.bias"])
+    return t.mean(dim=1) @ sd["linear_head.weight"].t() + sd["linear_head.bias"]
+
+
+def altvit_state(kind, image, patch, dim, depth, heads, mlp, classes, dim_head=64):
+    """Formula-valued state_dict with the reference's keys."""
+    from . import formula
+    names = ("1", "2", "3") if kind == "simple" else ("layernorm1", "linear", "layernorm2")
+    pd, inner = 3 * patch * patch, heads * dim_head
+    shapes = {f"to_patch_embedding.{names[0]}.weight": (pd,), f"to_patch_embedding.{names[0]}.bias": (pd,),
+              f"to_patch_embedding.{names[1]}.weight": (dim, pd), f"to_patch_embedding.{names[1]}.bias": (dim,),
+              f"to_patch_embedding.{names[2]}.weight": (dim,), f"to_patch_embedding.{names[2]}.bias": (dim,),
+              "transformer.norm.weight": (dim,), "transformer.norm.bias": (dim,),
+              "linear_head.weight": (classes, dim), "linear_head.bias": (classes,)}
+    for i in range(depth):
+        a, f = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1.net."
+        shapes.update({a + "norm.weight": (dim,), a + "norm.bias": (dim,), a + "to_qkv.weight": (3 * inner, dim),
+                       a + "to_out.weight": (dim, inner), f + "0.weight": (dim,), f + "0.bias": (dim,),
+                       f + "1.weight": (mlp, dim), f + "1.bias": (mlp,), f + "3.weight": (dim, mlp), f + "3.bias": (dim,)})
+    sd = {k: formula.param_value(k, shp) for k, shp in shapes.items()}
+    sd["pos_embedding"] = altvit_pos_embedding(kind, image // patch, dim)
+    return sd

@@ -143,7 +143,16 @@ class _Linear(Function):
 
 
 def linear(x, weight, bias=None, act=ops.ACT_NONE):
-    return _Linear.apply(_bf(x), _bf(weight), _bf(bias), act)
+    """y = act(x W^T + b).  Output widths that are not a multiple of 8 (a 10-class head) are computed on zero-padded
+    rows of W (16-byte output rows) and sliced back; the padding is differentiable torch plumbing."""
+    x, weight, bias = _bf(x), _bf(weight), _bf(bias)
+    out = weight.shape[0]
+    pad = (-out) % 8
+    if pad:
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, pad))
+        bias = torch.nn.functional.pad(bias, (0, pad)) if bias is not None else None
+        return _Linear.apply(x, weight, bias, act)[..., :out]
+    return _Linear.apply(x, weight, bias, act)
 
 
 class _LayerNorm(Function):
@@ -180,6 +189,28 @@ class _Gelu(Function):
 
 def gelu(x):
     return _Gelu.apply(_bf(x))
+
+
+class _Attention(Function):
+    """softmax(q k^T / sqrt(hd)) v per head on a packed projection [B, N, 3 * H * hd] (q | k | v thirds, head h at
+    columns h*hd.. of each third): the core of nn.MultiheadAttention and of altvit.Attention (altvit.py:131-142)."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_heads):
+        qkv = _c(qkv)
+        out, lse = ops.attention_fwd(qkv, n_heads)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.n_heads = n_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        return ops.attention_bwd(qkv, out, lse, _c(dout), ctx.n_heads), None
+
+
+def attention(qkv, n_heads):
+    return _Attention.apply(_bf(qkv), n_heads)
 
 
 # ----------------------------------------------------------------------------

@@ -269,3 +269,16 @@ def test_warmup_cosine_scheduler_values():
            [1e-6 + 0.5 * (1e-3 - 1e-6) * (1 + math.cos(math.pi * min(1.0, (s - 4) / 8))) for s in range(4, 15)]
     assert got == pytest.approx(want, rel=1e-12)
     assert Opt.param_groups[0]["lr"] == Opt.param_groups[1]["lr"] == got[-1] == pytest.approx(1e-6)
+
+
+def test_altvit_classes_have_the_reference_surface(golden_dir):
+    from oracle.cases import ALTVIT_CASES
+    import src.models.altvit as alt
+    with open(os.path.join(golden_dir, "altvit.json")) as f:
+        gold = json.load(f)
+    for name, (clsname, kw, _) in ALTVIT_CASES.items():
+        mod = getattr(alt, clsname)(**kw)
+        assert {k: list(v.shape) for k, v in mod.state_dict().items()} == gold[name]["keys"], name
+        assert abs(float(mod.pos_embedding.double().norm()) - gold[name]["pos_embedding_l2"]) < 1e-4 * gold[name]["pos_embedding_l2"]
+    with pytest.raises(AssertionError, match="power of 2"):
+        alt.HilbertViT(image_size=48, patch_size=4, num_classes=10, dim=64, depth=1, heads=1, mlp_dim=64)

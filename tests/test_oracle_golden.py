@@ -138,3 +138,35 @@ def test_spiral_and_2d_hilbert_tables_against_reference_fixture(golden_dir):
         assert np.array_equal(ocurves.flat_table("spiral", n), gold[f"spiral_{n}"]), n
     for n in HILBERT_T_N:
         assert np.array_equal(ocurves.flat_table("hilbert_t", n), gold[f"hilbert_t_{n}"]), n
+
+
+def _alt_cases():
+    from oracle.cases import ALTVIT_CASES
+    return sorted(ALTVIT_CASES)
+
+
+@pytest.mark.parametrize("name", _alt_cases())
+def test_altvit_oracle_against_reference_fixture(name, golden_dir):
+    """SimpleViT / HilbertViT (src/models/altvit.py): logits, loss, gradient norms and the positional embedding of the
+    fp32 restatement against what the reference classes produced on the same formula weights."""
+    from oracle.cases import ALTVIT_CASES
+    clsname, kw, batch = ALTVIT_CASES[name]
+    kind = "simple" if clsname == "SimpleViT" else "hilbert"
+    with open(os.path.join(golden_dir, "altvit.json")) as f:
+        gold = json.load(f)[name]
+    sd = vit_oracle.altvit_state(kind, kw["image_size"], kw["patch_size"], kw["dim"], kw["depth"], kw["heads"], kw["mlp_dim"],
+                                 kw["num_classes"])
+    assert {k: list(v.shape) for k, v in sd.items()} == gold["keys"]
+    assert abs(float(sd["pos_embedding"].double().norm()) - gold["pos_embedding_l2"]) < 1e-4 * gold["pos_embedding_l2"]
+    assert torch.allclose(sd["pos_embedding"].flatten()[:8], torch.tensor(gold["pos_embedding_head"]), atol=1e-5)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "pos_embedding"}
+    full = dict(sd, **leaves)
+    x = formula.image_batch(batch, 3, kw["image_size"], kw["image_size"])
+    logits = vit_oracle.altvit_forward(x, full, kind, kw["patch_size"], kw["heads"], kw["depth"])
+    assert torch.allclose(logits, torch.tensor(gold["logits"]), rtol=1e-3, atol=2e-4)
+    loss = vit_oracle.soft_target_ce(logits, formula.soft_targets(batch, kw["num_classes"]))
+    assert abs(float(loss.detach()) - gold["loss"]) < 1e-4 * abs(gold["loss"]) + 1e-5
+    loss.backward()
+    for k, want in gold["grad_norm"].items():
+        got = float(leaves[k].grad.double().norm())
+        assert abs(got - want) <= 2e-3 * want + 1e-7, (k, got, want)

@@ -232,3 +232,47 @@ def test_checkpoint_resume_continues_bit_exactly(tmp_path):
     train_step(model2, x, tgt, opt2)
     for k, v in model2.state_dict().items():
         assert torch.equal(v, want[k]), k
+
+
+def _alt_cases():
+    from oracle.cases import ALTVIT_CASES
+    return sorted(ALTVIT_CASES)
+
+
+@pytest.mark.parametrize("name", _alt_cases())
+def test_altvit_logits_loss_and_grads(name, golden_dir):
+    """SimpleViT / HilbertViT on the HIP kernels vs the fp32 oracle and the reference fixture (same tolerances as the
+    main model family)."""
+    from oracle.cases import ALTVIT_CASES
+    import src.models.altvit as alt
+    import sfcvit.functional as F
+    clsname, kw, batch = ALTVIT_CASES[name]
+    kind = "simple" if clsname == "SimpleViT" else "hilbert"
+    with open(os.path.join(golden_dir, "altvit.json")) as f:
+        gold = json.load(f)[name]
+    sd = vit_oracle.altvit_state(kind, kw["image_size"], kw["patch_size"], kw["dim"], kw["depth"], kw["heads"], kw["mlp_dim"],
+                                 kw["num_classes"])
+    model = getattr(alt, clsname)(**kw)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    x = formula.image_batch(batch, 3, kw["image_size"], kw["image_size"])
+    tgt = formula.soft_targets(batch, kw["num_classes"])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "pos_embedding"}
+    ref_logits = vit_oracle.altvit_forward(x, dict(sd, **leaves), kind, kw["patch_size"], kw["heads"], kw["depth"])
+    ref_loss = vit_oracle.soft_target_ce(ref_logits, tgt)
+    ref_loss.backward()
+    logits = model(x.cuda())
+    got = logits.float().cpu()
+    scale = ref_logits.detach().abs().max()
+    assert (got - ref_logits.detach()).abs().max() <= LOGIT_TOL * scale
+    assert (got - torch.tensor(gold["logits"])).abs().max() <= LOGIT_TOL * scale
+    loss = F.soft_target_cross_entropy(logits, tgt.cuda())
+    assert abs(float(loss.detach()) - gold["loss"]) <= 2e-3 * abs(gold["loss"]) + 2e-3
+    loss.backward()
+    for k, p in model.named_parameters():
+        g, gr = p.grad.float().cpu().flatten(), leaves[k].grad.flatten()
+        if float(gr.norm()) < 1e-6:
+            continue
+        cos = torch.dot(g, gr) / (g.norm() * gr.norm() + 1e-30)
+        assert cos >= 0.99, (k, float(cos))
+        assert abs(float(g.norm() / gr.norm()) - 1.0) <= 5e-2, k

@@ -163,6 +163,29 @@ def main():
     for n in HILBERT_T_N:
         extra[f"hilbert_t_{n}"] = HilbertEmbedding(n, 1, 3, 4).hilbert_indices.numpy().astype(np.int32)
     np.savez_compressed(os.path.join(GOLD, "curves_extra.npz"), **extra)
+    # ---- altvit (SimpleViT / HilbertViT) --------------------------------------------
+    from oracle.cases import ALTVIT_CASES
+    from src.models import altvit as ref_altvit
+    alt = {}
+    for name, (clsname, kw, batch) in ALTVIT_CASES.items():
+        mod = getattr(ref_altvit, clsname)(**kw).eval()
+        sd0 = mod.state_dict()
+        filled = formula.fill_state_dict(sd0)
+        filled["pos_embedding"] = sd0["pos_embedding"]           # computed buffer, not a weight
+        mod.load_state_dict(filled)
+        x = formula.image_batch(batch, 3, kw["image_size"], kw["image_size"])
+        tgt = formula.soft_targets(batch, kw["num_classes"])
+        logits = mod(x)
+        loss = torch.sum(-tgt * torch.nn.functional.log_softmax(logits, dim=-1), dim=-1).mean()
+        loss.backward()
+        grads = {k: float(p.grad.double().norm()) for k, p in mod.named_parameters()}
+        alt[name] = {"logits": logits.detach().tolist(), "loss": float(loss), "grad_norm": grads,
+                     "pos_embedding_l2": float(sd0["pos_embedding"].double().norm()),
+                     "pos_embedding_head": sd0["pos_embedding"].flatten()[:8].tolist(),
+                     "keys": {k: list(v.shape) for k, v in sd0.items()}}
+        print(name, "loss", float(loss))
+    with open(os.path.join(GOLD, "altvit.json"), "w") as f:
+        json.dump(alt, f)
     with open(os.path.join(GOLD, "state_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     return 0
