@@ -16,7 +16,7 @@ namespace {
 
 using namespace attn;
 
-constexpr int MAXF = 16, MAXC = 8, WAVES = THREADS / 64, MAXOWN = MAXF / WAVES;
+constexpr int MAXF = 16, MAXC = 8, WAVES = THREADS / 64;
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
