@@ -77,9 +77,12 @@ struct Cursor {            // the k-tile being staged for one operand: index in 
 };
 
 // One output row segment of 16 consecutive columns, in the documented order: bias, act, dropout, residual, dact, store.
+// `side` = the 16 bf16 of this row segment of the residual (RES) or of aux_in (DACT), loaded by the caller for ALL
+// rows before the first use: hipcc puts one `s_waitcnt vmcnt(0)` in front of the first use of an ordinary load while
+// LDS-DMA is in flight, so loading row by row paid one memory latency per row.
 template <int MASK>
 __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, int n, float (&v)[16], const float (&bv)[16],
-                                             uint32_t thresh, float keep_scale, float dact_scale) {
+                                             const u32x4 (&side)[2], uint32_t thresh, float keep_scale, float dact_scale) {
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] += bv[r];
     if (MASK & RELU) {
@@ -97,18 +100,16 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
         }
     }
     if (MASK & RES) {
-        const uint16_t *p = static_cast<const uint16_t *>(g.residual) + size_t(m) * g.ldr + n;
         float rv[16];
-        unpack8f(*reinterpret_cast<const u32x4 *>(p), rv);
-        unpack8f(*reinterpret_cast<const u32x4 *>(p + 8), rv + 8);
+        unpack8f(side[0], rv);
+        unpack8f(side[1], rv + 8);
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] += rv[r];
     }
     if (MASK & DACT) {
-        const uint16_t *p = static_cast<const uint16_t *>(g.aux_in) + size_t(m) * g.ldaux + n;
         float a[16];
-        unpack8f(*reinterpret_cast<const u32x4 *>(p), a);
-        unpack8f(*reinterpret_cast<const u32x4 *>(p + 8), a + 8);
+        unpack8f(side[0], a);
+        unpack8f(side[1], a + 8);
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = a[r] > 0.f ? v[r] * dact_scale : 0.f;
     }
@@ -246,13 +247,32 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
 #pragma unroll
             for (int r = 0; r < 16; r++) bv[r] = 0.f;
         }
-        static_for<0, NI>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            float v[16] = {acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3], acc[i][1][0], acc[i][1][1],
-                           acc[i][1][2], acc[i][1][3], acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3],
-                           acc[i][3][0], acc[i][3][1], acc[i][3][2], acc[i][3][3]};
-            epilogue_row<MASK>(g, m0 + 16 * i, n0, v, bv, thresh, keep_scale, dact_scale);
-        });
+        // rows in two batches (fragments 0-3, 4..NI-1): all of a batch's side-operand loads are issued before the
+        // first use, so the memory latency is paid twice per tile, not once per row; one batch of 8 rows spilled at
+        // NI = 8 with dropout + residual
+        const uint16_t *sp = (MASK & RES) ? static_cast<const uint16_t *>(g.residual) : static_cast<const uint16_t *>(g.aux_in);
+        const size_t ld_side = (MASK & RES) ? size_t(g.ldr) : size_t(g.ldaux);
+        auto batch = [&](auto i0c, auto i1c) __attribute__((always_inline)) {
+            constexpr int i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
+            u32x4 side[i1 - i0][2];
+            if (MASK & (RES | DACT)) {
+#pragma unroll
+                for (int i = i0; i < i1; i++) {
+                    const uint16_t *p = sp + size_t(m0 + 16 * i) * ld_side + n0;
+                    side[i - i0][0] = *reinterpret_cast<const u32x4 *>(p);
+                    side[i - i0][1] = *reinterpret_cast<const u32x4 *>(p + 8);
+                }
+            }
+            static_for<i0, i1>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                float v[16] = {acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3], acc[i][1][0], acc[i][1][1],
+                               acc[i][1][2], acc[i][1][3], acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3],
+                               acc[i][3][0], acc[i][3][1], acc[i][3][2], acc[i][3][3]};
+                epilogue_row<MASK>(g, m0 + 16 * i, n0, v, bv, side[i - i0], thresh, keep_scale, dact_scale);
+            });
+        };
+        batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        batch(std::integral_constant<int, 4>{}, std::integral_constant<int, NI>{});
         zero_acc();
     };
 

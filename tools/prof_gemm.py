@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Few launches of chosen GEMM shapes/kernels for rocprofv3 --pmc runs (see profiles/).
-usage: prof_gemm.py shape[,shape...] mode    (mode = force_generic value: 0 auto, 1 generic, 7 256x256, 6 256x128)"""
+usage: prof_gemm.py shape[,shape...] mode    (mode = force_generic value of include/sfcvit.h: 0 auto, 1 generic, 6 ring 256x128, 8 / 9 persistent 8-phase)"""
 import os
 import sys
 
