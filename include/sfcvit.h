@@ -144,9 +144,18 @@ typedef struct sfcvit_gemm_args {
     float dact_scale;      /* multiplies v together with dact (0 = 1): 1/(1-p) of a dropout that followed the ReLU */
     int32_t row_offset;    /* dropout mask row of C row m is m + row_offset (a GEMM computed as row slices
                               keeps one mask) */
+    void *colsum_out;      /* NULL, or [N]: column sums over m of the epilogue's result (the bias gradient of the Linear
+                              that produced the A operand's gradient chain, e.g. db1 = colsum(dh)): fp32, or bf16 when
+                              colsum_bf16 != 0.  Fused into the persistent kernel's epilogue when that kernel runs
+                              (partials of the fp32 values in `workspace`, then a fixed-order reduce); otherwise a
+                              separate pass over the stored bf16 C.  Needs workspace_bytes >=
+                              sfcvit_gemm_colsum_workspace(M, N); not with split-K or fp32 C. */
+    int32_t colsum_bf16;
 } sfcvit_gemm_args;
 
 int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);
+/* HOST: workspace bytes for a call with colsum_out. */
+int64_t sfcvit_gemm_colsum_workspace(int M, int N);
 /* HOST: name of the kernel the calling thread's last sfcvit_gemm launched, as rocprofv3 prints it (without the
  * namespace), e.g. "gemm8p_kernel<7, 6>" -- lets a benchmark key its live timings by kernel symbol. */
 int sfcvit_last_gemm_kernel(char *buf, int n);

@@ -17,6 +17,10 @@ int check_launch(const char *what);
 // Which GEMM kernel the calling thread's last sfcvit_gemm launched (sfcvit_last_gemm_kernel formats it as the symbol
 // rocprofv3 shows): family 1 gemm8p_kernel<a, b>, 2 gemm8p_km_kernel, 3 gemm256_kernel<a, b, c, d>, 4 gemm_kernel<a, b, c>.
 void note_gemm_kernel(int family, int a = 0, int b = 0, int c = 0, int d = 0);
+bool gemm_fused_colsum();     // the kernel noted last was the 8-phase kernel with column sums in its epilogue
+
+// rowwise.hip: out[n] = sum over `nparts` rows of part[nparts][N] in a fixed order; out fp32 or bf16.
+int launch_colsum_reduce(const float *part, int nparts, int N, void *out, int out_bf16, void *stream);
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -123,7 +123,29 @@ extern "C" int64_t sfcvit_gemm_workspace(int M, int N, int splitk) {
     return slabs * M * N * int64_t(sizeof(float));
 }
 
+extern "C" int64_t sfcvit_gemm_colsum_workspace(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    const int64_t fused = (int64_t(M) / 112 + 2) * N * int64_t(sizeof(float));      // partial rows of the 8-phase epilogue
+    const int64_t separate = sfcvit_colsum_workspace(M, N);
+    return fused > separate ? fused : separate;
+}
+
+static int gemm_impl(const sfcvit_gemm_args *a, void *stream);
+
 extern "C" int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream) {
+    using namespace sfcvit;
+    if (a && a->colsum_out) {
+        if (a->c_is_f32 || a->splitk > 1) return fail(SFCVIT_EINVAL, "gemm: colsum_out needs a bf16 C and no split-K");
+        if (!a->workspace || a->workspace_bytes < sfcvit_gemm_colsum_workspace(a->M, a->N) || !aligned16(a->workspace))
+            return fail(SFCVIT_EINVAL, "gemm: colsum_out needs sfcvit_gemm_colsum_workspace(M, N) bytes of workspace");
+    }
+    if (int rc = gemm_impl(a, stream)) return rc;
+    if (a->colsum_out && !gemm_fused_colsum())   // the kernel that ran had no fused column sums: one pass over the stored C
+        return sfcvit_colsum(a->c, a->M, a->N, a->ldc, a->colsum_out, a->colsum_bf16, a->workspace, a->workspace_bytes, stream);
+    return SFCVIT_OK;
+}
+
+static int gemm_impl(const sfcvit_gemm_args *a, void *stream) {
     using namespace sfcvit;
     if (!a || !a->a || !a->b || !a->c) return fail(SFCVIT_EINVAL, "gemm: null operand");
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return fail(SFCVIT_EINVAL, "gemm: M=%d N=%d K=%d", a->M, a->N, a->K);

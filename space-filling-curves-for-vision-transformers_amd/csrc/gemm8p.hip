@@ -45,7 +45,7 @@ using namespace gemm_core;
 namespace p8 {
 
 constexpr int T = 512, HALF = 16384, KTB = 65536, LDS_BYTES = 2 * KTB;
-enum { RELU = 1, DROP = 2, RES = 4, DACT = 8 };
+enum { RELU = 1, DROP = 2, RES = 4, DACT = 8, CSUM = 16 };
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -80,6 +80,15 @@ struct Cursor {            // the k-tile being staged for one operand: index in 
 // `side` = the 16 bf16 of this row segment of the residual (RES) or of aux_in (DACT), loaded by the caller for ALL
 // rows before the first use: hipcc puts one `s_waitcnt vmcnt(0)` in front of the first use of an ordinary load while
 // LDS-DMA is in flight, so loading row by row paid one memory latency per row.
+// Sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane of the row.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
 template <int MASK>
 __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, int n, float (&v)[16], const float (&bv)[16],
                                              const u32x4 (&side)[2], uint32_t thresh, float keep_scale, float dact_scale) {
@@ -252,6 +261,9 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
         // NI = 8 with dropout + residual
         const uint16_t *sp = (MASK & RES) ? static_cast<const uint16_t *>(g.residual) : static_cast<const uint16_t *>(g.aux_in);
         const size_t ld_side = (MASK & RES) ? size_t(g.ldr) : size_t(g.ldaux);
+        float cs[16];                                           // CSUM: this lane's 16 columns summed over its NI rows
+#pragma unroll
+        for (int r = 0; r < 16; r++) cs[r] = 0.f;
         auto batch = [&](auto i0c, auto i1c) __attribute__((always_inline)) {
             constexpr int i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
             u32x4 side[i1 - i0][2];
@@ -269,10 +281,27 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
                                acc[i][1][2], acc[i][1][3], acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3],
                                acc[i][3][0], acc[i][3][1], acc[i][3][2], acc[i][3][3]};
                 epilogue_row<MASK>(g, m0 + 16 * i, n0, v, bv, side[i - i0], thresh, keep_scale, dact_scale);
+                if (MASK & CSUM) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) cs[r] += v[r];      // the fp32 values that were just stored as bf16
+                }
             });
         };
         batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
         batch(std::integral_constant<int, 4>{}, std::integral_constant<int, NI>{});
+        if (MASK & CSUM) {
+            // column sums of this wave's GR x 64 block: across the 16 lanes that hold the same columns (one DPP row),
+            // then lane nl == 0 of every row writes 16 floats of partial row (2 * tile row + wave group); a fixed-order
+            // pass over the (M / GR) partial rows follows the kernel (no atomics)
+#pragma unroll
+            for (int r = 0; r < 16; r++) cs[r] = row16_sum(cs[r]);
+            if (nl == 0) {
+                float *pp = static_cast<float *>(g.workspace) + size_t(2 * (tile / NT) + wr) * g.N + n0;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++)
+                    *reinterpret_cast<f32x4 *>(pp + 4 * r4) = f32x4{cs[4 * r4], cs[4 * r4 + 1], cs[4 * r4 + 2], cs[4 * r4 + 3]};
+            }
+        }
         zero_acc();
     };
 
@@ -541,6 +570,7 @@ int launch_mask(const sfcvit_gemm_args &a, int mask, int grid, hipStream_t s) {
     case RELU: return launch<NI, RELU>(a, grid, s);
     case RELU | DROP: return launch<NI, RELU | DROP>(a, grid, s);
     case DACT: return launch<NI, DACT>(a, grid, s);
+    case DACT | CSUM: return launch<NI, DACT | CSUM>(a, grid, s);
     default: return -1;
     }
 }
@@ -597,6 +627,7 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     if (a.dropout_p > 0.f) mask |= DROP;
     if (a.residual) mask |= RES;
     if (a.dact == SFCVIT_ACT_RELU) mask |= DACT;
+    if (a.colsum_out) mask |= CSUM;                          // built with DACT only; other combinations fall back
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -618,7 +649,14 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     if (!ni) return -1;
     if (a.force_generic == 8) ni = (a.M % 256 == 0) ? 8 : ni;          // tests: pin the 256-row tile
     if (a.force_generic == 9) { if (a.M % 224) return -1; ni = 7; }    // tests: pin the 224-row tile
-    return ni == 8 ? launch_mask<8>(a, mask, cus, s) : launch_mask<7>(a, mask, cus, s);
+    if (mask & CSUM) {
+        const int64_t need = int64_t(a.M / (16 * ni)) * a.N * int64_t(sizeof(float));
+        if (!a.workspace || a.workspace_bytes < need || (reinterpret_cast<uintptr_t>(a.workspace) & 15)) return -1;
+    }
+    const int rc = ni == 8 ? launch_mask<8>(a, mask, cus, s) : launch_mask<7>(a, mask, cus, s);
+    if (rc == 0 && (mask & CSUM))
+        return launch_colsum_reduce(static_cast<const float *>(a.workspace), a.M / (16 * ni), a.N, a.colsum_out, a.colsum_bf16, s);
+    return rc;
 }
 
 }  // namespace sfcvit

@@ -626,6 +626,14 @@ void colsum_plan(int M, int N, int &col_blocks, int &row_blocks, int &rpb) {
 }
 }  // namespace
 
+namespace sfcvit {
+int launch_colsum_reduce(const float *part, int nparts, int N, void *out, int out_bf16, void *stream) {
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream), part, nparts, N,
+                       out, out_bf16);
+    return check_launch("colsum reduce");
+}
+}  // namespace sfcvit
+
 extern "C" int64_t sfcvit_colsum_workspace(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
     int cb, rb, rpb;

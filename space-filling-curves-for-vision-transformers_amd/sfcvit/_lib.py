@@ -30,7 +30,7 @@ class GemmArgs(ctypes.Structure):
                 ("c_is_f32", c_int32), ("splitk", c_int32), ("workspace", c_void_p),
                 ("workspace_bytes", c_int64), ("force_generic", c_int32),
                 ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("dact_scale", c_float),
-                ("row_offset", c_int32)]
+                ("row_offset", c_int32), ("colsum_out", c_void_p), ("colsum_bf16", c_int32)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -62,6 +62,7 @@ SIGNATURES = {
     "sfcvit_gemm_workspace": (c_int64, [c_int, c_int, c_int]),
     "sfcvit_patch_embed_workspace": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sfcvit_transpose": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sfcvit_gemm_colsum_workspace": (c_int64, [c_int, c_int]),
     "sfcvit_last_gemm_kernel": (c_int, [ctypes.c_char_p, c_int]),
     "sfcvit_colsum_workspace": (c_int64, [c_int, c_int]),
     "sfcvit_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),

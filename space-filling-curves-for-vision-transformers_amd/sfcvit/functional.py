@@ -299,8 +299,13 @@ class _EncoderLayer(Function):
         ds2, dg2, dbt2, df, db2 = ln_bwd(dy2, s2, mean2, rstd2, n2_w, n2_b, b2, s2_)
         dw2 = wg(df, h, w2)
         # h is stored after relu + dropout: (h > 0) is the joint mask, 1/(1-p) the dropout scale
-        dh = ops.gemm_dx(df, w2, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p))
-        dw1, db1 = wg(dh, x1, w1), _bgrad(dh, b1)
+        # ... and the bias gradient of linear1 is the column sum of dh: fused into that GEMM's epilogue
+        b1_slot = _slot(b1)
+        dh, db1 = ops.gemm_dx(df, w2, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p),
+                              colsum=b1_slot if b1_slot is not None else True)
+        if b1_slot is None:
+            db1 = db1.to(_BF16)
+        dw1 = wg(dh, x1, w1)
         dx1 = ops.gemm_dx(dh, w1, residual=ds2)
         ds1, dg1, dbt1, da, dbo = ln_bwd(dx1, s1, mean1, rstd1, n1_w, n1_b, out_b, s1_)
         o2 = o.view(B * N, D)

@@ -127,9 +127,10 @@ def next_seed():
 
 def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, residual=None,
          aux_in=None, dact=ACT_NONE, want_aux=False, out_f32=False, splitk=None, force_generic=False,
-         dropout_p=0.0, dropout_seed=0, dact_scale=1.0, out=None, row_offset=0):
+         dropout_p=0.0, dropout_seed=0, dact_scale=1.0, out=None, row_offset=0, colsum=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  a: [M,K] (or [K,M] if a_kmajor),
-    b: [N,K] (or [K,N] if b_kmajor), bf16.  Returns C (and the pre-activation if want_aux)."""
+    b: [N,K] (or [K,N] if b_kmajor), bf16.  Returns C (and the pre-activation if want_aux; and the column sums of C
+    if `colsum` is True (fp32 [N]) or a bf16 [N] tensor to write them into, e.g. a bias-gradient slot)."""
     _rows2d(a, _BF16, "gemm a")
     _rows2d(b, _BF16, "gemm b")
     M, K = (a.shape[1], a.shape[0]) if a_kmajor else (a.shape[0], a.shape[1])
@@ -173,9 +174,20 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
         args.workspace, args.workspace_bytes = ws.data_ptr(), nbytes
     args.splitk = splitk
     args.force_generic = int(force_generic)
+    cs = None
+    if colsum is not None and colsum is not False:
+        cs = torch.empty(N, device=a.device, dtype=torch.float32) if colsum is True else colsum
+        if cs.numel() != N or not cs.is_contiguous() or cs.dtype not in (torch.float32, _BF16):
+            raise ValueError("gemm colsum: contiguous fp32 or bf16 [N] expected")
+        nbytes = lib.sfcvit_gemm_colsum_workspace(M, N)
+        ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), nbytes
+        args.colsum_out, args.colsum_bf16 = cs.data_ptr(), int(cs.dtype == _BF16)
     key = "gemm %s" % {(False, False): "y=x.W^T (k-contig, k-contig)", (False, True): "dx=dy.W (k-contig, k-major)",
                        (True, True): "dW=dy^T.x (k-major, k-major)", (True, False): "(k-major, k-contig)"}[(a_kmajor, b_kmajor)]
     check(_launch(key, 2.0 * M * N * K, lambda: lib.sfcvit_gemm(ctypes.byref(args), _stream())), "sfcvit_gemm")
+    if cs is not None:
+        return (c, aux, cs) if want_aux else (c, cs)
     return (c, aux) if want_aux else c
 
 

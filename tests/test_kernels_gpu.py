@@ -433,3 +433,34 @@ def test_attention_wide_heads_dropout_and_limits(ops):
         ops.attention_fwd(bf(torch.randn(1, 16, 3 * 96, device="cuda")), 1)
     with pytest.raises(Exception, match="LDS"):                 # 576 tokens x head dim 128 do not fit one CU's LDS
         ops.attention_fwd(bf(torch.randn(1, 576, 3 * 128, device="cuda")), 1)
+
+
+@pytest.mark.parametrize("M,N,K", [(896, 512, 256), (1024, 768, 128), (200, 136, 64)])
+def test_gemm_fused_column_sums(ops, M, N, K):
+    """colsum= : column sums of the epilogue's result next to C (bias gradient of the previous Linear).  Fused into
+    the persistent kernel's epilogue for the activation-gradient variant (first two shapes), a separate pass otherwise
+    (third shape: off the tile grid) -- same C either way, sums within fp32-vs-bf16 rounding of each other."""
+    g = torch.Generator(device="cuda").manual_seed(41)
+    a = bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) * 0.1)
+    aux = bf(torch.randn(M, N, device="cuda", generator=g))
+    kw = dict(aux_in=aux, dact=ops.ACT_RELU, dact_scale=1.0 / 0.9)
+    c0 = ops.gemm(a, w, **kw)
+    c, cs = ops.gemm(a, w, colsum=True, **kw)
+    assert torch.equal(c, c0) and cs.dtype == torch.float32
+    # the fused path sums the fp32 values before their bf16 rounding (closer to the exact sum), the separate pass sums
+    # the stored bf16 C: both within sqrt(M) * bf16 rounding of the exact fp32 column sums
+    exact = ((a.float() @ w.float().t()) * (aux.float() > 0) / 0.9).sum(0)
+    tol = 4.0 * math.sqrt(M) * 2.0 ** -9 * c0.float().pow(2).mean().sqrt()
+    assert (cs - exact).abs().max() <= tol
+    assert (cs - c0.float().sum(0)).abs().max() <= tol
+    slot = torch.zeros(N, device="cuda", dtype=torch.bfloat16)
+    c2, cs2 = ops.gemm(a, w, colsum=slot, **kw)
+    assert cs2.data_ptr() == slot.data_ptr() and torch.equal(c2, c0)
+    close(slot, exact)
+    for _ in range(3):                                  # fixed-order reduction: bit-reproducible
+        assert torch.equal(ops.gemm(a, w, colsum=True, **kw)[1], cs)
+    # a variant without a fused form (bias + colsum) takes the separate pass
+    bias = bf(torch.randn(N, device="cuda", generator=g))
+    c3, cs3 = ops.gemm(a, w, bias=bias, colsum=True)
+    close(cs3, c3.float().sum(0), rel=2e-3, abs_scale=2e-3)
