@@ -14,6 +14,10 @@ namespace {
 
 using namespace attn;
 
+// Tried and not kept: the same kernels for N <= 576 (ViT-L at 384 x 384: K + V = 144 KiB of LDS, a 36-fragment score
+// row in registers, one workgroup of four waves per CU).  Correct, but 14.0 vs 8.0 ms per ViT-L step forward and 26.7 vs
+// 22.8 ms backward against the tiled kernels of attention.hip: at one wave per SIMD nothing hides the exp / reduction
+// latencies between the MFMA bursts.
 constexpr int MAXF = 16;   // 16-row fragments per sequence (N <= 256)
 constexpr int MAXC = 8;    // 32-row chunks
 

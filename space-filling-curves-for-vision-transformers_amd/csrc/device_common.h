@@ -1,5 +1,6 @@
 // Device-side helpers for gfx950 (CDNA4): wave = 64 lanes, bf16 MFMA 16x16x32.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -98,6 +99,16 @@ __device__ __forceinline__ void drop_keep2(uint32_t row_key, uint32_t pair_in_ro
 // two instructions after the MFMA and returned pre-MFMA values -- a run-to-run varying row max).
 // 16 states cover the 8-pass bf16 MFMAs; call it wherever control flow separates the two.
 __device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
+
+// Compile-time loop: register arrays (MFMA accumulators, score rows) must only ever be indexed by constants; a loop
+// the unroller gives up on turns the index into a runtime value and the array into scratch memory.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // 64-lane butterfly reductions.
 __device__ __forceinline__ float wave_sum(float v) {

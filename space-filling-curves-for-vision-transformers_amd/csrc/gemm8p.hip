@@ -61,16 +61,6 @@ __device__ __forceinline__ void bar() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Compile-time loop: the accumulator array must only ever be indexed by constants (a loop the unroller gives up on
-// -- the epilogue body is large -- turns acc[i] into a runtime index and the whole array into scratch memory).
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 struct Cursor {            // the k-tile being staged for one operand: index in the tile list, k offset, origin
     int tile, k0;
     const uint16_t *p;
