@@ -4,7 +4,12 @@
 //   * tile (32*NI) x 256 x 64 with NI = 8 or 7 (256 or 224 rows: the height that wastes least of the last round
 //     of tiles on 256 CUs; M = 50176 = 196 * 256 = 224 * 224), 8 waves = 2 wave groups (row halves) x 4 column
 //     blocks, wave tile (16*NI) x 64, 16x16x32 MFMA.
-//   * one workgroup per CU walks a list of output tiles (round r -> tile r*G + u).  The k-tile stream does not stop
+//   * one workgroup per CU walks output tiles that it draws from a per-XCD atomic counter (tiles are dealt to the XCDs
+//     in chunks of 32 consecutive ones, so the workgroups of an XCD share A row panels in its L2).  Drawing instead of
+//     a fixed round-robin costs one atomic per tile and makes the kernel insensitive to CUs that are busy with
+//     something else when it starts -- an RCCL all-reduce overlapped with backward occupies some: with fixed lists
+//     the workgroups that must wait for those CUs start a whole kernel late and double its duration.  Which workgroup
+//     computes a tile does not change the tile's result.  The k-tile stream does not stop
 //     at a tile boundary: operands go HBM/L2 -> LDS by LDS-DMA into a ring of two 64 KiB k-tiles (four 16 KiB
 //     half-tiles each: A rows of group 0 / group 1, B columns 0-127 / 128-255) and the ring keeps prefetching the
 //     next tile's first k-tiles under the current tile's last phases and its epilogue -- no prologue per tile.
@@ -35,7 +40,9 @@
 // -1 from gemm8p_dispatch and takes the older kernels (gemm256.hip, gemm.hip).
 #include "common_host.h"
 #include "gemm_core.h"
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 namespace sfcvit {
 namespace {
@@ -118,7 +125,7 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
 }
 
 template <int NI, int MASK>
-__global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
+__global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, unsigned *__restrict__ counters) {
     constexpr int BM = 32 * NI, GR = 16 * NI;               // tile rows, rows per wave group
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: ring of 2 x [A0 | A1 | B0 | B1]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3;
@@ -126,12 +133,37 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
     const int K = g.K, NT = g.N / 256, ntiles = (g.M / BM) * NT, KT = K / 64;
     const uint16_t *A = static_cast<const uint16_t *>(g.a);
     const uint16_t *B = static_cast<const uint16_t *>(g.b);
-    // The 32 workgroups of an XCD (blockIdx % 8) take 32 consecutive tiles of a round: they share A row panels
-    // in that XCD's L2.
-    const int G = gridDim.x;
-    const int u = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    if (u >= ntiles) return;
-    const int my_tiles = (ntiles - u + G - 1) / G;
+    // Tile queue.  XCD x (blockIdx % 8: where the dispatcher puts this workgroup, a locality heuristic only) owns the
+    // tiles  (l / 32) * G + 32 x + l % 32  for l = 0, 1, ...; counters[x] is the next l.  A workgroup holds two tiles:
+    // the one it computes and the next one (whose first k-tiles the ring prefetches); thread 0 draws the one after
+    // that in the epilogue -- next to the bias / residual loads, whose wait it shares -- and publishes it through a
+    // 4-entry ring in LDS (-1 = none left), which every wave reads at least two k-tiles (K >= 256) and many barriers
+    // later.  counters[8] counts finished workgroups; the last one zeroes the counters for the next launch.
+    const int G = gridDim.x, per_xcd = G >> 3, xcd = blockIdx.x & 7;
+    int *const tq = reinterpret_cast<int *>(smem + LDS_BYTES);
+    auto tile_of = [&](unsigned l) __attribute__((always_inline)) {
+        const long t = long(l / unsigned(per_xcd)) * G + xcd * per_xcd + int(l % unsigned(per_xcd));
+        return t < ntiles ? int(t) : -1;
+    };
+    auto finish = [&]() __attribute__((always_inline)) {
+        if (tid == 0) {
+            const unsigned old = atomicAdd(counters + 8, 1u);
+            if (old == unsigned(G) - 1u) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) counters[i] = 0u;
+            }
+        }
+    };
+    if (tid == 0) {
+        const unsigned l0 = atomicAdd(counters + xcd, 2u);
+        tq[0] = tile_of(l0);
+        tq[1] = tile_of(l0 + 1u);
+    }
+    __syncthreads();
+    int tile_cur = __builtin_amdgcn_readfirstlane(tq[0]);   // the tile being computed (wave-uniform: keep it scalar)
+    if (tile_cur < 0) { finish(); return; }
+    const int tile_first = tile_cur;
+    int t = 0;                                  // tiles finished by this workgroup
 
     // --- staging: this thread's two 16-byte pieces of a half-tile (LDS rows r1 and r1 + 64) ---
     //   A0: LDS row 64 grp + w  <-  tile row grp*GR + w            (w < 64: fragments 0-3 of wave group grp)
@@ -148,16 +180,16 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
     const size_t b_h1 = size_t(8) * g.ldb;
     char *const lds_piece = smem + tid * 16;
 
-    auto cursor_at = [&](int t, bool is_a) __attribute__((always_inline)) {
+    auto cursor_at = [&](int seq, int tile, bool is_a) __attribute__((always_inline)) {
         Cursor c;
-        c.tile = t;
+        c.tile = seq;                                          // position in this workgroup's sequence of tiles
         c.k0 = 0;
-        const int tile = (t < my_tiles ? t : 0) * G + u;       // past the end: re-stage the first tile (never consumed)
+        if (tile < 0) tile = tile_first;                       // past the end: re-stage the first tile (never consumed)
         c.p = is_a ? A + size_t(tile / NT) * BM * g.lda : B + size_t(tile % NT) * 256 * g.ldb;
         return c;
     };
     auto advance = [&](Cursor &c, bool is_a) __attribute__((always_inline)) {
-        if (c.k0 + 64 == K) c = cursor_at(c.tile + 1, is_a);
+        if (c.k0 + 64 == K) c = cursor_at(c.tile + 1, __builtin_amdgcn_readfirstlane(tq[(c.tile + 1) & 3]), is_a);
         else { c.k0 += 64; c.p += 64; }
     };
     auto stage_a = [&](const Cursor &c, int buf, int h) __attribute__((always_inline)) {
@@ -233,8 +265,10 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
     const uint32_t thresh = (MASK & DROP) ? drop_thresh(g.dropout_p) : 0u;
     const float keep_scale = (MASK & DROP) ? 1.f / (1.f - g.dropout_p) : 1.f;
     const float dact_scale = g.dact_scale != 0.f ? g.dact_scale : 1.f;
-    auto epilogue = [&](int t) __attribute__((always_inline)) {
-        const int tile = t * G + u;
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        const int tile = tile_cur;
+        unsigned drawn = 0;
+        if (tid == 0) drawn = atomicAdd(counters + xcd, 1u);    // wave group 0's epilogue only (tid 0 is in it)
         const int m0 = (tile / NT) * BM + wr * GR + nl, n0 = (tile % NT) * 256 + wc * 64 + q * 16;
         mfma_fence();
         float bv[16];
@@ -292,11 +326,12 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
                     *reinterpret_cast<f32x4 *>(pp + 4 * r4) = f32x4{cs[4 * r4], cs[4 * r4 + 1], cs[4 * r4 + 2], cs[4 * r4 + 3]};
             }
         }
+        if (tid == 0) tq[(t + 2) & 3] = tile_of(drawn);
         zero_acc();
     };
 
     // --- prologue: the state the loop expects at phase 0 of k-tile 0 ---
-    Cursor ca = cursor_at(0, true), cb = cursor_at(0, false);
+    Cursor ca = cursor_at(0, tile_cur, true), cb = cursor_at(0, tile_cur, false);
     stage_b(cb, 0, 0); stage_a(ca, 0, 0); stage_a(ca, 0, 1); stage_b(cb, 0, 1);
     advance(ca, true);
     advance(cb, false);
@@ -314,7 +349,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
     // phase's fragment reads one phase early, under the previous phase's MFMAs (role-swapping register sets): no
     // gain (1051 / 813 / 977 / 1073 vs 1043 / 819 / 985 / 1116 TFLOP/s on the four forward shapes) and spills at
     // 256 registers -- LDS read latency is not what the load section of a phase waits for.
-    auto ktile = [&](int buf, bool last, int t) __attribute__((always_inline)) {
+    auto ktile = [&](int buf, bool last) __attribute__((always_inline)) {
         // phase 0: a0 x b0
         read_b(fb0, buf, 0);
         read_a0(buf);
@@ -344,21 +379,26 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g) {
         wait_vm<4>();                         // the whole next k-tile has landed
         bar();
         mma0(fb1, 1);
-        if (last && wr == 1) epilogue(t);
+        if (last && wr == 1) epilogue();
         bar();
-        if (last && wr == 0) epilogue(t);
+        if (last && wr == 0) epilogue();
     };
-    int kt = 0, t = 0;
-    const int total = my_tiles * KT;
-    for (int gk = 0; gk < total; gk += 2) {
-        ktile(0, false, t);
+    int kt = 0;
+    for (;;) {
+        ktile(0, false);
         kt += 2;
         const bool last = kt == KT;
-        ktile(1, last, t);
-        if (last) { kt = 0; t++; }
+        ktile(1, last);
+        if (last) {
+            kt = 0;
+            t++;
+            tile_cur = __builtin_amdgcn_readfirstlane(tq[t & 3]);
+            if (tile_cur < 0) break;
+        }
     }
     if (wr == 0) bar();
     wait_vm<0>();
+    finish();
 }
 
 
@@ -537,17 +577,34 @@ __global__ __launch_bounds__(T) void gemm8p_km_kernel(const sfcvit_gemm_args g, 
             *reinterpret_cast<f32x4 *>(slab + size_t((i >> 2) * 128 + (i & 3) * 16) * g.N + (j >> 1) * 128 + (j & 1) * 16) = acc[i][j];
 }
 
+// Nine zero-initialised counters per stream (tile queues of the 8 XCDs + finished workgroups); every launch leaves
+// them zero again.  Allocated on the first launch on a stream (not capturable: warm up before capturing a hipGraph).
+unsigned *queue_counters(hipStream_t s) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, unsigned *> per_stream;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_stream.find(s);
+    if (it != per_stream.end()) return it->second;
+    unsigned *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), 64) != hipSuccess || hipMemset(p, 0, 64) != hipSuccess) return nullptr;
+    per_stream[s] = p;
+    return p;
+}
+
 template <int NI, int MASK>
 int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
+    constexpr int LDS_TOTAL = LDS_BYTES + 64;                  // ring + the 4-entry tile ring
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
             return check_launch("gemm8p attribute");
         attr_set = true;
     }
+    unsigned *counters = queue_counters(s);
+    if (!counters) return fail(SFCVIT_ELAUNCH, "gemm8p: could not allocate the tile-queue counters");
     note_gemm_kernel(1, NI, MASK);
-    hipLaunchKernelGGL((gemm8p_kernel<NI, MASK>), dim3(grid), dim3(T), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm8p_kernel<NI, MASK>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters);
     return check_launch("gemm8p");
 }
 
@@ -608,7 +665,7 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     using namespace p8;
     if (a.a_kmajor || a.b_kmajor || splits != 1 || a.c_is_f32 || a.aux_out) return -1;
     if (a.act == SFCVIT_ACT_GELU || a.dact == SFCVIT_ACT_GELU) return -1;
-    if (a.N % 256 || a.K % 128 || a.lda % 8 || a.ldb % 8 || a.ldc % 8) return -1;
+    if (a.N % 256 || a.K % 128 || a.K < 256 || a.lda % 8 || a.ldb % 8 || a.ldc % 8) return -1;
     if (a.residual && (a.ldr % 8 || (reinterpret_cast<uintptr_t>(a.residual) & 15))) return -1;
     if (a.dact && (a.ldaux % 8 || (reinterpret_cast<uintptr_t>(a.aux_in) & 15))) return -1;
     if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return -1;

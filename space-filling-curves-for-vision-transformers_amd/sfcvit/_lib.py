@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfcvit_hip.so")
+LIB_PATH = os.environ.get("SFCVIT_LIB", os.path.join(_HERE, "libsfcvit_hip.so"))   # override: A/B builds of the kernels
 
 c_void_p, c_int, c_int32, c_int64, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
                                               ctypes.c_int64, ctypes.c_float)
@@ -63,6 +63,7 @@ SIGNATURES = {
     "sfcvit_patch_embed_workspace": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sfcvit_transpose": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sfcvit_gemm_colsum_workspace": (c_int64, [c_int, c_int]),
+    "sfcvit_test_occupy": (c_int, [c_int, ctypes.c_longlong, c_void_p, c_void_p]),
     "sfcvit_last_gemm_kernel": (c_int, [ctypes.c_char_p, c_int]),
     "sfcvit_colsum_workspace": (c_int64, [c_int, c_int]),
     "sfcvit_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),

@@ -313,11 +313,11 @@ def test_gemm_row_slices_share_one_dropout_mask(ops):
 # persistent 8-phase kernel (gemm8p.hip): force_generic 8 = 256-row tiles, 9 = 224-row tiles
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,mode", [
-    (256, 256, 128, 8),          # one tile, two k-tiles
+    (256, 256, 256, 8),          # one tile, four k-tiles (the shortest k loop the kernel takes)
     (512, 512, 256, 8),          # 4 tiles
-    (224, 256, 128, 9),          # one 224-row tile
+    (224, 256, 256, 9),          # one 224-row tile
     (448, 768, 384, 9),
-    (256 * 37, 256 * 7, 128, 8),     # 259 tiles on 256 workgroups: the second round of the tile list, short k loop
+    (256 * 37, 256 * 7, 256, 8),     # 259 tiles for 256 workgroups: some draw a third tile, short k loop
     (224 * 40, 256 * 7, 256, 9),     # 280 tiles
     (256 * 12, 768, 768, 8),         # ViT-B k loop
 ])
@@ -435,7 +435,7 @@ def test_attention_wide_heads_dropout_and_limits(ops):
         ops.attention_fwd(bf(torch.randn(1, 576, 3 * 128, device="cuda")), 1)
 
 
-@pytest.mark.parametrize("M,N,K", [(896, 512, 256), (1024, 768, 128), (200, 136, 64)])
+@pytest.mark.parametrize("M,N,K", [(896, 512, 256), (1024, 768, 384), (200, 136, 64)])
 def test_gemm_fused_column_sums(ops, M, N, K):
     """colsum= : column sums of the epilogue's result next to C (bias gradient of the previous Linear).  Fused into
     the persistent kernel's epilogue for the activation-gradient variant (first two shapes), a separate pass otherwise

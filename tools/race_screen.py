@@ -13,8 +13,8 @@ from sfcvit import ops  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 g = torch.Generator(device="cuda").manual_seed(0)
 bad = 0
-for (M, N, K) in [(50176, 768, 768), (50176, 2304, 768), (50176, 768, 3072), (256 * 300, 256, 128), (224 * 17, 512, 384),
-                  (36864, 1024, 1024), (256, 256, 128)]:
+for (M, N, K) in [(50176, 768, 768), (50176, 2304, 768), (50176, 768, 3072), (256 * 300, 256, 256), (224 * 17, 512, 384),
+                  (36864, 1024, 1024), (256, 256, 256), (256 * 3, 256 * 5, 512)]:
     a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     w = (torch.randn(N, K, device="cuda", generator=g) * 0.1).bfloat16()
     b = torch.randn(N, device="cuda", generator=g).bfloat16()
