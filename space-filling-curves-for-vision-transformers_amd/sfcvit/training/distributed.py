@@ -12,7 +12,7 @@ the averaged gradient without an extra pass or a second collective.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): ViT-B has 218 MB of bf16
 gradients per step, i.e. ~0.4-2.5 ms on the wire against >= 20 ms of backward, so a
-few large buckets (default 64 MB) keep per-collective latency negligible and every
+few large buckets (default 32 MB: the last one, which cannot overlap with anything, costs ~0.2 ms) keep per-collective latency negligible and every
 link busy.
 """
 import torch
@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, optimizer, bucket_bytes=64 << 20, group=None):
+    def __init__(self, optimizer, bucket_bytes=32 << 20, group=None):
         self.opt = optimizer
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
