@@ -582,15 +582,27 @@ __global__ __launch_bounds__(T) void gemm8p_km_kernel(const sfcvit_gemm_args g, 
 }
 
 // Nine zero-initialised counters per stream (tile queues of the 8 XCDs + finished workgroups); every launch leaves
-// them zero again.  Allocated on the first launch on a stream (not capturable: warm up before capturing a hipGraph).
+// them zero again, and launches on one stream are ordered, so a stream can keep its slot for ever.  The slots come
+// from one pool allocated at the first call (which must therefore not sit inside a hipGraph capture: warm up first);
+// handing a slot to a new stream -- a capture stream, say -- allocates nothing.
 unsigned *queue_counters(hipStream_t s) {
+    constexpr int SLOTS = 1024, SLOT_UINTS = 16;
     static std::mutex mu;
     static std::unordered_map<hipStream_t, unsigned *> per_stream;
+    static unsigned *pool = nullptr;
+    static int next = 0;
     std::lock_guard<std::mutex> lock(mu);
     auto it = per_stream.find(s);
     if (it != per_stream.end()) return it->second;
-    unsigned *p = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&p), 64) != hipSuccess || hipMemset(p, 0, 64) != hipSuccess) return nullptr;
+    if (!pool) {
+        if (hipMalloc(reinterpret_cast<void **>(&pool), size_t(SLOTS) * SLOT_UINTS * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(pool, 0, size_t(SLOTS) * SLOT_UINTS * sizeof(unsigned)) != hipSuccess) {
+            pool = nullptr;
+            return nullptr;
+        }
+    }
+    if (next >= SLOTS) return nullptr;           // 1024 distinct streams in one process: not a case worth more code
+    unsigned *p = pool + size_t(next++) * SLOT_UINTS;
     per_stream[s] = p;
     return p;
 }

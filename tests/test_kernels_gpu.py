@@ -464,3 +464,31 @@ def test_gemm_fused_column_sums(ops, M, N, K):
     bias = bf(torch.randn(N, device="cuda", generator=g))
     c3, cs3 = ops.gemm(a, w, bias=bias, colsum=True)
     close(cs3, c3.float().sum(0), rel=2e-3, abs_scale=2e-3)
+
+
+def test_ops_are_hipgraph_capturable(ops):
+    """The reference wraps its model in torch.compile(mode="reduce-overhead") (main.py:284), i.e. HIP graphs: nothing in
+    the C ABI may allocate, synchronise or touch the host at launch time.  Capture a GEMM on the persistent kernel (its
+    tile-queue counters come from a pre-allocated pool), a LayerNorm and an attention forward on a fresh capture
+    stream, replay on new inputs."""
+    g = torch.Generator(device="cuda").manual_seed(51)
+    a = bf(torch.randn(512, 256, device="cuda", generator=g))
+    w = bf(torch.randn(512, 256, device="cuda", generator=g) * 0.1)
+    bias = bf(torch.randn(512, device="cuda", generator=g))
+    gam, bet = bf(torch.ones(512, device="cuda")), bf(torch.zeros(512, device="cuda"))
+    qkv = bf(torch.randn(2, 64, 3 * 128, device="cuda", generator=g))
+    ops.gemm(a, w, bias=bias)                       # warm-up outside the capture (first call creates the pool)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = ops.gemm(a, w, bias=bias)
+        z, _, _ = ops.layernorm_fwd(y, gam, bet, 1e-5)
+        o, _ = ops.attention_fwd(qkv, 2)
+    a2 = bf(torch.randn(512, 256, device="cuda", generator=g))
+    q2 = bf(torch.randn(2, 64, 3 * 128, device="cuda", generator=g))
+    a.copy_(a2)
+    qkv.copy_(q2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ops.gemm(a2, w, bias=bias))
+    assert torch.equal(z, ops.layernorm_fwd(y, gam, bet, 1e-5)[0])
+    assert torch.equal(o, ops.attention_fwd(q2, 2)[0])
