@@ -52,6 +52,9 @@ using namespace gemm_core;
 namespace p8 {
 
 constexpr int T = 512, HALF = 16384, KTB = 65536, LDS_BYTES = 2 * KTB;
+// gemm8p_kernel's LDS beyond the ring: the 4-entry tile ring, one [16][128 B] store patch per wave, the bias vector
+constexpr int LDS_TQ = LDS_BYTES, LDS_PATCH = LDS_TQ + 64, LDS_BIAS = LDS_PATCH + 8 * 2048, LDS_MAX = 160 * 1024;
+constexpr int BIAS_MAX_N = (LDS_MAX - LDS_BIAS) / 2;
 enum { RELU = 1, DROP = 2, RES = 4, DACT = 8, CSUM = 16 };
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -86,11 +89,22 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Where a lane's packed output goes: the wave's [16 rows][64 columns] of one fragment row pass through a wave-private
+// LDS patch ([16][128 B], 16-byte chunk index XOR-ed with row & 7) so that the global stores are row-contiguous.
+struct StoreMap {
+    int wa;          // LDS address of this lane's first 16 bytes in the fragment layout (row nl, chunk 2 q); second: wa ^ 16
+    int ra;          // LDS address read back: row lane >> 3 (and + 8 at offset 1024), chunk lane & 7
+    long coff;       // element offset of (row lane >> 3, column 8 (lane & 7)) relative to (row nl, column 16 q)
+};
+
 template <int MASK>
 __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, int n, float (&v)[16], const float (&bv)[16],
-                                             const u32x4 (&side)[2], uint32_t thresh, float keep_scale, float dact_scale) {
+                                             const u32x4 (&side)[2], uint32_t thresh, float keep_scale, float dact_scale,
+                                             const StoreMap &sm) {
+    if (!(MASK & DACT)) {                                       // gradient GEMMs carry no bias (the dispatcher checks)
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] += bv[r];
+        for (int r = 0; r < 16; r++) v[r] += bv[r];
+    }
     if (MASK & RELU) {
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = fmaxf(v[r], 0.f);
@@ -120,8 +134,47 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
         for (int r = 0; r < 16; r++) v[r] = a[r] > 0.f ? v[r] * dact_scale : 0.f;
     }
     uint16_t *c = static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n;
+#ifdef P8_LAB_NOSTORE      // lab builds only: the loop without the tile stores (results are wrong)
+    if (v[0] != 12345.678f) return;
+#endif
+#ifdef P8_LAB_STORE_SMALL  // lab builds only: the same store instructions into a 256-row window (stays in L2; results are wrong)
+    c = static_cast<uint16_t *>(g.c) + size_t(m & 255) * g.ldc + n;
+#endif
+#ifdef P8_LAB_STORE_NT     // lab builds only: non-temporal stores
+    __builtin_nontemporal_store(u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])}, reinterpret_cast<u32x4 *>(c));
+    __builtin_nontemporal_store(u32x4{pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])}, reinterpret_cast<u32x4 *>(c + 8));
+    return;
+#endif
+#ifdef P8_LAB_STORE_DIRECT // lab builds only: the fragment layout stored as it is (16 B per lane, 16 rows per quarter-wave)
     *reinterpret_cast<u32x4 *>(c) = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
     *reinterpret_cast<u32x4 *>(c + 8) = u32x4{pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+#else
+    // In the fragment layout a store instruction touches 64 different 64-byte segments (16 rows per quarter-wave,
+    // 16 bytes each): the vector-memory pipe takes them one by one, and the next tile's LDS-DMA queues behind them.
+    // Through the patch an instruction writes 8 rows x 128 contiguous bytes.  LDS operations of one wave execute in
+    // order, so write -> read needs no wait in between; inline asm because hipcc would put `s_waitcnt vmcnt(0)` in
+    // front of ordinary LDS accesses while LDS-DMA (and the previous row's stores) are in flight.
+    // (the reads return into the registers the writes took their data from: the LDS pipe has consumed them by then)
+    u32x4 w0 = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    u32x4 w1 = {pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+    asm volatile("ds_write_b128 %2, %0\n\tds_write_b128 %3, %1\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "+v"(w0), "+v"(w1)
+                 : "v"(sm.wa), "v"(sm.wa ^ 16), "v"(sm.ra)
+                 : "memory");
+    c += sm.coff;
+#ifdef P8_LAB_NOSTORE2     // lab builds only: everything but the global store instructions (results are wrong)
+    if (g.M > 0) { asm volatile("" ::"v"(w0), "v"(w1)); return; }
+#endif
+#ifdef P8_LAB_STORE_HALF   // lab builds only: the same number of store instructions, half the bytes (results are wrong)
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_lab;
+    *reinterpret_cast<u32x2_lab *>(c) = u32x2_lab{w0[0], w0[1]};
+    *reinterpret_cast<u32x2_lab *>(c + size_t(8) * g.ldc) = u32x2_lab{w1[0], w1[1]};
+    return;
+#endif
+    *reinterpret_cast<u32x4 *>(c) = w0;
+    *reinterpret_cast<u32x4 *>(c + size_t(8) * g.ldc) = w1;
+#endif
 }
 
 template <int NI, int MASK>
@@ -136,11 +189,10 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     // Tile queue.  XCD x (blockIdx % 8: where the dispatcher puts this workgroup, a locality heuristic only) owns the
     // tiles  (l / 32) * G + 32 x + l % 32  for l = 0, 1, ...; counters[x] is the next l.  A workgroup holds two tiles:
     // the one it computes and the next one (whose first k-tiles the ring prefetches); thread 0 draws the one after
-    // that in the epilogue -- next to the bias / residual loads, whose wait it shares -- and publishes it through a
-    // 4-entry ring in LDS (-1 = none left), which every wave reads at least two k-tiles (K >= 256) and many barriers
-    // later.  counters[8] counts finished workgroups; the last one zeroes the counters for the next launch.
+    // that one epilogue ahead and publishes it in the next epilogue through a 4-entry ring in LDS (-1 = none left),
+    // which every wave reads at least two k-tiles (K >= 256) and many barriers later.  counters[8] counts finished workgroups; the last one zeroes the counters for the next launch.
     const int G = gridDim.x, per_xcd = G >> 3, xcd = blockIdx.x & 7;
-    int *const tq = reinterpret_cast<int *>(smem + LDS_BYTES);
+    int *const tq = reinterpret_cast<int *>(smem + LDS_TQ);
     auto tile_of = [&](unsigned l) __attribute__((always_inline)) {
         const long t = long(l / unsigned(per_xcd)) * G + xcd * per_xcd + int(l % unsigned(per_xcd));
         return t < ntiles ? int(t) : -1;
@@ -154,6 +206,13 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
             }
         }
     };
+#ifdef P8_LAB_STAGGER      // lab builds only (tools/gemm_lab/README.md): start the workgroups of an XCD in P8_LAB_SLOTS time slots
+                           // spread over P8_LAB_STAGGER ns per k-tile
+    {
+        const uint64_t until = wall_clock64() + uint64_t((blockIdx.x >> 3) % P8_LAB_SLOTS) * uint64_t(KT) * P8_LAB_STAGGER / (10 * P8_LAB_SLOTS);
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     if (tid == 0) {
         // two separate draws: every workgroup of the XCD first takes one tile of the first chunk of 32, then one of the
         // second.  (One draw of two would hand a workgroup two column tiles of the same A panel to compute one after
@@ -163,9 +222,22 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         const unsigned l1 = atomicAdd(counters + xcd, 1u);
         tq[1] = tile_of(l1);
     }
+    // the bias vector, once, into LDS: an epilogue then never waits for a global load on its account (vector-memory
+    // operations retire in order, so such a wait also drains the LDS-DMA and the stores issued around it)
+    const bool has_bias = !(MASK & DACT) && g.bias != nullptr;     // the DACT variants (gradient GEMMs) carry none
+    if (has_bias)
+        for (int i = tid; i < g.N / 8; i += T)
+            *reinterpret_cast<u32x4 *>(smem + LDS_BIAS + i * 16) = static_cast<const u32x4 *>(g.bias)[i];
     __syncthreads();
+
     int tile_cur = __builtin_amdgcn_readfirstlane(tq[0]);   // the tile being computed (wave-uniform: keep it scalar)
     if (tile_cur < 0) { finish(); return; }
+    // thread 0's draw in flight: issued in one epilogue (here for the first), read in the next, a whole tile later.
+    // (Read in the epilogue that issues it, the wait for the atomic's return -- which, vector-memory operations
+    // retiring in order, is also a wait for every LDS-DMA issued before it -- stalled wave 0, and through the
+    // barriers the workgroup, once per tile.)  The exit path waits for vmcnt(0) before finish().
+    unsigned drawn = 0;
+    if (tid == 0) drawn = atomicAdd(counters + xcd, 1u);
     const int tile_first = tile_cur;
     int t = 0;                                  // tiles finished by this workgroup
 
@@ -271,15 +343,26 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     const float dact_scale = g.dact_scale != 0.f ? g.dact_scale : 1.f;
     auto epilogue = [&]() __attribute__((always_inline)) {
         const int tile = tile_cur;
-        unsigned drawn = 0;
-        if (tid == 0) drawn = atomicAdd(counters + xcd, 1u);    // wave group 0's epilogue only (tid 0 is in it)
+        StoreMap sm;                                            // built here: not live across the k-loop
+        {
+            int le = lane;
+            asm volatile("" : "+v"(le));                        // keeps the compiler from hoisting these out of the k-loop
+            const int patch = LDS_PATCH + wid * 2048, r0 = le >> 3, ch = le & 7, qe = le >> 4, ne = le & 15;
+            sm.wa = patch + ne * 128 + (((2 * qe) ^ (ne & 7)) << 4);
+            sm.ra = patch + r0 * 128 + ((ch ^ r0) << 4);
+            sm.coff = long(r0 - ne) * g.ldc + (8 * ch - 16 * qe);
+        }
+        if (tid == 0) {                                         // wave group 0's epilogue only (tid 0 is in it)
+            tq[(t + 2) & 3] = tile_of(drawn);
+            drawn = atomicAdd(counters + xcd, 1u);
+        }
         const int m0 = (tile / NT) * BM + wr * GR + nl, n0 = (tile % NT) * 256 + wc * 64 + q * 16;
         mfma_fence();
-        float bv[16];
-        if (g.bias) {
-            const uint16_t *bp = static_cast<const uint16_t *>(g.bias) + n0;
+        float bv[16];                                           // this lane's 16 bias values, from the LDS copy
+        if (has_bias) {
+            const char *bp = smem + LDS_BIAS + n0 * 2;
             unpack8f(*reinterpret_cast<const u32x4 *>(bp), bv);
-            unpack8f(*reinterpret_cast<const u32x4 *>(bp + 8), bv + 8);
+            unpack8f(*reinterpret_cast<const u32x4 *>(bp + 16), bv + 8);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) bv[r] = 0.f;
@@ -308,7 +391,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
                 float v[16] = {acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3], acc[i][1][0], acc[i][1][1],
                                acc[i][1][2], acc[i][1][3], acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3],
                                acc[i][3][0], acc[i][3][1], acc[i][3][2], acc[i][3][3]};
-                epilogue_row<MASK>(g, m0 + 16 * i, n0, v, bv, side[i - i0], thresh, keep_scale, dact_scale);
+                epilogue_row<MASK>(g, m0 + 16 * i, n0, v, bv, side[i - i0], thresh, keep_scale, dact_scale, sm);
                 if (MASK & CSUM) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) cs[r] += v[r];      // the fp32 values that were just stored as bf16
@@ -330,7 +413,9 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
                     *reinterpret_cast<f32x4 *>(pp + 4 * r4) = f32x4{cs[4 * r4], cs[4 * r4 + 1], cs[4 * r4 + 2], cs[4 * r4 + 3]};
             }
         }
-        if (tid == 0) tq[(t + 2) & 3] = tile_of(drawn);
+#ifdef P8_LAB_ACKWAIT      // lab builds only: wait for the stores' acknowledgements before the next tile
+        wait_vm<0>();
+#endif
         zero_acc();
     };
 
@@ -609,11 +694,11 @@ unsigned *queue_counters(hipStream_t s) {
 
 template <int NI, int MASK>
 int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
-    constexpr int LDS_TOTAL = LDS_BYTES + 64;                  // ring + the 4-entry tile ring
+    const int LDS_TOTAL = LDS_BIAS + (a.bias ? a.N * 2 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess)
             return check_launch("gemm8p attribute");
         attr_set = true;
     }
@@ -691,6 +776,8 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     if (a.residual) mask |= RES;
     if (a.dact == SFCVIT_ACT_RELU) mask |= DACT;
     if (a.colsum_out) mask |= CSUM;                          // built with DACT only; other combinations fall back
+    if ((mask & DACT) && a.bias) return -1;                  // the DACT variants leave the bias out (register room)
+    if (a.bias && a.N > BIAS_MAX_N) return -1;               // the bias vector lives in LDS
     static int cus = 0;
     if (!cus) {
         int dev = 0;

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(512) void store_tiles(uint16_t *C, const uint16_t *
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
-    if (PRO) {   // one k-tile of DMA like the GEMM prologue
+    if (PRO && PRO < 4) {   // one k-tile of DMA like the GEMM prologue
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = i * 512 + tid, row = p >> 3, c = p & 7;
@@ -27,7 +27,24 @@ __global__ __launch_bounds__(512) void store_tiles(uint16_t *C, const uint16_t *
         __syncthreads();
     }
     const int wm = wave >> 2, wn = wave & 3;
-    if (PRO < 2) {
+    if (PRO >= 4) {
+        // register epilogues of gemm8p: lane (q = lane >> 4, nl = lane & 15) holds row 16 i + nl of fragment row i.
+        //   4: its 16 consecutive columns 16 q .. 16 q + 15 (two 16-byte stores 16 B apart)           [the product]
+        //   5: columns 8 q .. 8 q + 7 and 32 + 8 q .. (two stores 64 B apart: a store instruction covers 64-byte runs)
+        const int q4 = lane >> 4, nl = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            u32x4 v = {uint32_t(i), uint32_t(q4), 3u, 4u};
+            uint16_t *c = C + size_t(m0 + wm * 128 + 16 * i + nl) * N + n0 + wn * 64;
+            if (PRO == 4) {
+                *reinterpret_cast<u32x4 *>(c + 16 * q4) = v;
+                *reinterpret_cast<u32x4 *>(c + 16 * q4 + 8) = v;
+            } else {
+                *reinterpret_cast<u32x4 *>(c + 8 * q4) = v;
+                *reinterpret_cast<u32x4 *>(c + 8 * q4 + 32) = v;
+            }
+        }
+    } else if (PRO < 2) {
     // wave tile 128 x 64: 16 instructions, each 8 rows x 128 B
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -71,10 +88,10 @@ int main(int argc, char **argv) {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     dim3 grid((M / 256) * (N / 256)), block(512);
-    for (int pro = 0; pro < 4; pro++)
+    for (int pro = 0; pro < 6; pro++)
         for (int lds : {0, 81920, 131072}) {
             if (pro && lds < 32768) continue;
-            auto k = pro == 0 ? store_tiles<0> : pro == 1 ? store_tiles<1> : pro == 2 ? store_tiles<2> : store_tiles<3>;
+            auto k = pro == 0 ? store_tiles<0> : pro == 1 ? store_tiles<1> : pro == 2 ? store_tiles<2> : pro == 3 ? store_tiles<3> : pro == 4 ? store_tiles<4> : store_tiles<5>;
             (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             for (int i = 0; i < 2; i++) hipLaunchKernelGGL(k, grid, block, lds, 0, C, A, M, N, K);
             (void)hipEventRecord(e0);
