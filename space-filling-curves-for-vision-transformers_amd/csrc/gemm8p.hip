@@ -177,13 +177,30 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
 #endif
 }
 
+#ifdef P8_LAB_TRACE         // lab builds only: shader-clock stamps of workgroup P8_LAB_TRACE, waves 0 and 4, through LDS
+__device__ unsigned long long p8_trace[2][256];
+#define P8_STAMP()                                                                                                   \
+    do {                                                                                                             \
+        if ((tid & 255) == 0 && blockIdx.x == P8_LAB_TRACE && tr_n < 256)                                           \
+            reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 8192)[(tid >> 8) * 256 + tr_n] = __builtin_amdgcn_s_memtime(); \
+        tr_n++;                                                                                                      \
+    } while (0)
+#else
+#define P8_STAMP()
+#endif
+
 template <int NI, int MASK>
 __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, unsigned *__restrict__ counters) {
     constexpr int BM = 32 * NI, GR = 16 * NI;               // tile rows, rows per wave group
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: ring of 2 x [A0 | A1 | B0 | B1]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3;
+    // wid through readfirstlane: the compiler then knows that wr / wc (and the branches on them) are wave-uniform, and
+    // keeps what those branches update -- the staging cursors -- in scalar registers
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 2, wc = wid & 3;
     const int q = lane >> 4, nl = lane & 15;
     const int K = g.K, NT = g.N / 256, ntiles = (g.M / BM) * NT, KT = K / 64;
+#ifdef P8_LAB_TRACE
+    int tr_n = 0;
+#endif
     const uint16_t *A = static_cast<const uint16_t *>(g.a);
     const uint16_t *B = static_cast<const uint16_t *>(g.b);
     // Tile queue.  XCD x (blockIdx % 8: where the dispatcher puts this workgroup, a locality heuristic only) owns the
@@ -195,7 +212,9 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     int *const tq = reinterpret_cast<int *>(smem + LDS_TQ);
     auto tile_of = [&](unsigned l) __attribute__((always_inline)) {
         const long t = long(l / unsigned(per_xcd)) * G + xcd * per_xcd + int(l % unsigned(per_xcd));
-        return t < ntiles ? int(t) : -1;
+        // published as (row tile << 16) | column tile: the divisions by NT are done here, by thread 0 off the critical
+        // path, not by every wave when its staging cursor crosses into the tile (measured: ~1000 clocks per tile)
+        return t < ntiles ? int((unsigned(t) / unsigned(NT)) << 16 | (unsigned(t) % unsigned(NT))) : -1;
     };
     auto finish = [&]() __attribute__((always_inline)) {
         if (tid == 0) {
@@ -250,34 +269,59 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     const int sc = (lane & 7) ^ ((r1 >> 1) & 7);                 // source chunk that lands in LDS chunk lane & 7
     const int w1 = (r1 < GR - 64) ? r1 : r1 - 16;
     const int b_row = (r1 >> 5) * 64 + ((r1 & 15) >> 2) * 16 + ((r1 >> 4) & 1) * 4 + (r1 & 3);
-    const size_t offA0a = size_t(r1) * g.lda + sc * 8, offA0b = offA0a + size_t(GR) * g.lda;
-    const size_t offA1a = size_t(64 + w1) * g.lda + sc * 8, offA1b = offA1a + size_t(GR) * g.lda;
-    const size_t offB0a = size_t(b_row) * g.ldb + sc * 8, offB0b = offB0a + size_t(128) * g.ldb;
-    const size_t b_h1 = size_t(8) * g.ldb;
-    char *const lds_piece = smem + tid * 16;
+    // per-thread byte offsets (32 bits: the dispatcher bounds 256 rows x ld), added to wave-uniform bases so that the
+    // LDS-DMA takes its scalar-base + 32-bit-offset form: three offset registers and no 64-bit vector adds in the loop
+    const uint32_t voffA0 = (uint32_t(r1) * uint32_t(g.lda) + sc * 8) * 2, voffA1 = (uint32_t(64 + w1) * uint32_t(g.lda) + sc * 8) * 2;
+    const uint32_t voffB = (uint32_t(b_row) * uint32_t(g.ldb) + sc * 8) * 2;
+    const size_t a_second = size_t(GR) * g.lda, b_second = size_t(128) * g.ldb, b_h1 = size_t(8) * g.ldb;
 
     auto cursor_at = [&](int seq, int tile, bool is_a) __attribute__((always_inline)) {
         Cursor c;
         c.tile = seq;                                          // position in this workgroup's sequence of tiles
         c.k0 = 0;
         if (tile < 0) tile = tile_first;                       // past the end: re-stage the first tile (never consumed)
-        c.p = is_a ? A + size_t(tile / NT) * BM * g.lda : B + size_t(tile % NT) * 256 * g.ldb;
+        c.p = is_a ? A + size_t(tile >> 16) * BM * g.lda : B + size_t(tile & 0xFFFF) * 256 * g.ldb;
         return c;
     };
+    // Where the cursors go when they leave the current tile: the operand origins of the workgroup's next tile, worked
+    // out (queue entry from LDS, two 64-bit multiplies) during the first k-tile of every tile, behind that phase's
+    // MFMAs -- done at the crossing itself it cost every wave ~800 clocks per tile (measured with P8_LAB_TRACE).
+    const uint16_t *next_a = nullptr, *next_b = nullptr;
+    auto set_next = [&](int seq) __attribute__((always_inline)) {
+        const Cursor na = cursor_at(seq, __builtin_amdgcn_readfirstlane(tq[seq & 3]), true);
+        const Cursor nb = cursor_at(seq, __builtin_amdgcn_readfirstlane(tq[seq & 3]), false);
+        next_a = na.p;
+        next_b = nb.p;
+    };
     auto advance = [&](Cursor &c, bool is_a) __attribute__((always_inline)) {
-        if (c.k0 + 64 == K) c = cursor_at(c.tile + 1, __builtin_amdgcn_readfirstlane(tq[(c.tile + 1) & 3]), is_a);
+        if (c.k0 + 64 == K) { c.tile++; c.k0 = 0; c.p = is_a ? next_a : next_b; }
         else { c.k0 += 64; c.p += 64; }
     };
+    // The LDS-DMA is issued from inline asm (scalar base + 32-bit lane offset, LDS base of the wave in M0), not through
+    // __builtin_amdgcn_global_load_lds: while hipcc (ROCm 7.2) knows of an LDS-DMA in flight, every s_waitcnt it
+    // inserts for an ordinary load is vmcnt(0) -- in the epilogue that meant waiting for the stores just issued to be
+    // acknowledged before the next batch of residual rows could be used.  Unaware of the DMA it counts (vmcnt(n) with
+    // n = the younger operations it knows of), which is never too weak: vector-memory operations retire in order and
+    // the DMA it does not count only add younger entries.  All waits that concern the DMA itself are explicit
+    // (wait_vm<>), as before.
+    const int m0_wave = wid * 1024;
+    auto dma16 = [&](const uint16_t *base, uint32_t voff, int lds) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(voff), "s"(base), "s"(lds)
+                     : "memory");
+    };
     auto stage_a = [&](const Cursor &c, int buf, int h) __attribute__((always_inline)) {
-        char *d = lds_piece + buf * KTB + h * HALF;
-        __builtin_amdgcn_global_load_lds((gptr_t)(c.p + (h ? offA1a : offA0a)), (lptr_t)d, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(c.p + (h ? offA1b : offA0b)), (lptr_t)(d + 8192), 16, 0, 0);
+        const int d = m0_wave + buf * KTB + h * HALF;
+        const uint32_t vo = h ? voffA1 : voffA0;
+        dma16(c.p, vo, d);
+        dma16(c.p + a_second, vo, d + 8192);
     };
     auto stage_b = [&](const Cursor &c, int buf, int h) __attribute__((always_inline)) {
         const uint16_t *p = c.p + (h ? b_h1 : 0);
-        char *d = lds_piece + buf * KTB + 2 * HALF + h * HALF;
-        __builtin_amdgcn_global_load_lds((gptr_t)(p + offB0a), (lptr_t)d, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(p + offB0b), (lptr_t)(d + 8192), 16, 0, 0);
+        const int d = m0_wave + buf * KTB + 2 * HALF + h * HALF;
+        dma16(p, voffB, d);
+        dma16(p + b_second, voffB, d + 8192);
     };
 
     // --- fragment reads: lane = (row nl, k chunk q) of a 16 x 32 fragment; the second k-step is the chunk ^ 4 ---
@@ -341,22 +385,28 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     const uint32_t thresh = (MASK & DROP) ? drop_thresh(g.dropout_p) : 0u;
     const float keep_scale = (MASK & DROP) ? 1.f / (1.f - g.dropout_p) : 1.f;
     const float dact_scale = g.dact_scale != 0.f ? g.dact_scale : 1.f;
+    auto draw = [&]() __attribute__((always_inline)) {        // wave group 0, before its epilogue (tid 0 is in it)
+        if (tid == 0) {
+            tq[(t + 2) & 3] = tile_of(drawn);
+            drawn = atomicAdd(counters + xcd, 1u);
+        }
+    };
     auto epilogue = [&]() __attribute__((always_inline)) {
+        P8_STAMP();
         const int tile = tile_cur;
-        StoreMap sm;                                            // built here: not live across the k-loop
+        // Everything lane-dependent is rebuilt here from the thread index behind an empty asm: left to itself the
+        // compiler hoists it out of the k-loop, where there is no register to keep it in.
+        int te = tid;
+        asm volatile("" : "+v"(te));
+        const int le = te & 63, qe = le >> 4, ne = le & 15;
+        StoreMap sm;
         {
-            int le = lane;
-            asm volatile("" : "+v"(le));                        // keeps the compiler from hoisting these out of the k-loop
-            const int patch = LDS_PATCH + wid * 2048, r0 = le >> 3, ch = le & 7, qe = le >> 4, ne = le & 15;
+            const int patch = LDS_PATCH + wid * 2048, r0 = le >> 3, ch = le & 7;
             sm.wa = patch + ne * 128 + (((2 * qe) ^ (ne & 7)) << 4);
             sm.ra = patch + r0 * 128 + ((ch ^ r0) << 4);
             sm.coff = long(r0 - ne) * g.ldc + (8 * ch - 16 * qe);
         }
-        if (tid == 0) {                                         // wave group 0's epilogue only (tid 0 is in it)
-            tq[(t + 2) & 3] = tile_of(drawn);
-            drawn = atomicAdd(counters + xcd, 1u);
-        }
-        const int m0 = (tile / NT) * BM + wr * GR + nl, n0 = (tile % NT) * 256 + wc * 64 + q * 16;
+        const int m0 = (tile >> 16) * BM + wr * GR + ne, n0 = (tile & 0xFFFF) * 256 + wc * 64 + qe * 16;
         mfma_fence();
         float bv[16];                                           // this lane's 16 bias values, from the LDS copy
         if (has_bias) {
@@ -367,9 +417,8 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
 #pragma unroll
             for (int r = 0; r < 16; r++) bv[r] = 0.f;
         }
-        // rows in two batches (fragments 0-3, 4..NI-1): all of a batch's side-operand loads are issued before the
-        // first use, so the memory latency is paid twice per tile, not once per row; one batch of 8 rows spilled at
-        // NI = 8 with dropout + residual
+        // All side-operand loads (residual / aux_in rows) are issued before the first use and before any store: one
+        // memory latency per tile, and no wait that has an older store in front of it.
         const uint16_t *sp = (MASK & RES) ? static_cast<const uint16_t *>(g.residual) : static_cast<const uint16_t *>(g.aux_in);
         const size_t ld_side = (MASK & RES) ? size_t(g.ldr) : size_t(g.ldaux);
         float cs[16];                                           // CSUM: this lane's 16 columns summed over its NI rows
@@ -398,16 +447,20 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
                 }
             });
         };
-        batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-        batch(std::integral_constant<int, 4>{}, std::integral_constant<int, NI>{});
+        if constexpr (NI == 8 && (MASK & (DROP | RES)) == (DROP | RES)) {   // no registers for 8 rows beside the hash
+            batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+            batch(std::integral_constant<int, 4>{}, std::integral_constant<int, NI>{});
+        } else {
+            batch(std::integral_constant<int, 0>{}, std::integral_constant<int, NI>{});
+        }
         if (MASK & CSUM) {
             // column sums of this wave's GR x 64 block: across the 16 lanes that hold the same columns (one DPP row),
             // then lane nl == 0 of every row writes 16 floats of partial row (2 * tile row + wave group); a fixed-order
             // pass over the (M / GR) partial rows follows the kernel (no atomics)
 #pragma unroll
             for (int r = 0; r < 16; r++) cs[r] = row16_sum(cs[r]);
-            if (nl == 0) {
-                float *pp = static_cast<float *>(g.workspace) + size_t(2 * (tile / NT) + wr) * g.N + n0;
+            if (ne == 0) {
+                float *pp = static_cast<float *>(g.workspace) + size_t(2 * (tile >> 16) + wr) * g.N + n0;
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++)
                     *reinterpret_cast<f32x4 *>(pp + 4 * r4) = f32x4{cs[4 * r4], cs[4 * r4 + 1], cs[4 * r4 + 2], cs[4 * r4 + 3]};
@@ -417,6 +470,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         wait_vm<0>();
 #endif
         zero_acc();
+        P8_STAMP();
     };
 
     // --- prologue: the state the loop expects at phase 0 of k-tile 0 ---
@@ -424,13 +478,15 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     stage_b(cb, 0, 0); stage_a(ca, 0, 0); stage_a(ca, 0, 1); stage_b(cb, 0, 1);
     advance(ca, true);
     advance(cb, false);
-    stage_b(cb, 1, 0); stage_a(ca, 1, 0);
-    wait_vm<4>();                             // k-tile 0
+    stage_b(cb, 1, 0); stage_a(ca, 1, 0); stage_a(ca, 1, 1); stage_b(cb, 1, 1);
+    advance(ca, true);
+    advance(cb, false);
+    wait_vm<8>();                             // k-tile 0
     bar();
     if (wr == 1) bar();                       // wave group 1 runs one barrier behind group 0
     zero_acc();
 
-    // One k-tile g in buffer `buf`.  On entry `ca` and `cb` are k-tile g+1 (its A0 / B0 already issued).
+    // One k-tile g in buffer `buf`.  On entry k-tile g+1 is issued in full and `ca` / `cb` are k-tile g+2.
     // One counted wait per k-tile (phase 3, vmcnt(4): everything but the two half-tiles issued last has landed, i.e.
     // the whole next k-tile).  Waiting per half-tile just before its first use (vmcnt(8) in phases 0, 1 and 3) measured
     // 2-5 % slower in the same process; it also keeps the epilogue's stores -- vector-memory operations that retire
@@ -438,23 +494,34 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     // phase's fragment reads one phase early, under the previous phase's MFMAs (role-swapping register sets): no
     // gain (1051 / 813 / 977 / 1073 vs 1043 / 819 / 985 / 1116 TFLOP/s on the four forward shapes) and spills at
     // 256 registers -- LDS read latency is not what the load section of a phase waits for.
-    auto ktile = [&](int buf, bool last) __attribute__((always_inline)) {
+    // Tile boundary.  Vector-memory operations retire in order, so a counted wait right after an epilogue also waits
+    // for the epilogue's stores to be acknowledged -- measured: as long as two to three k-tiles on a busy L2, with
+    // the MFMAs idle meanwhile.  Therefore A1 / B1 of k-tile g+2 are issued at the END of k-tile g (both groups are
+    // through with these halves by then), which at a tile boundary is before the epilogue: everything the first
+    // k-tile of the next tile waits for is older than the stores, and its wait can leave them outstanding --
+    // vmcnt(4 + NSTORE).  The next wait is a whole k-tile later.
+    constexpr int NSTORE = 2 * NI + ((MASK & CSUM) ? 4 : 0);  // store instructions per wave and epilogue
+    auto stage_next = [&](int buf) __attribute__((always_inline)) {
+        stage_a(ca, buf, 1);
+        advance(ca, true);
+        stage_b(cb, buf, 1);
+        advance(cb, false);
+        __builtin_amdgcn_sched_barrier(0);    // the address temporaries die here, not under the next phase's fragment reads
+    };
+    auto ktile = [&](int buf, bool first, bool last) __attribute__((always_inline)) {
         // phase 0: a0 x b0
         read_b(fb0, buf, 0);
         read_a0(buf);
-        stage_a(ca, buf ^ 1, 1);
-        advance(ca, true);
         bar();
         wait_lgkm<0>();
         mma0(fb0, 0);
         bar();
         // phase 1: a1 x b0
         read_a1(buf);
-        stage_b(cb, buf ^ 1, 1);
-        advance(cb, false);
         bar();
         wait_lgkm<0>();
         mma1(fb0, 0);
+        if (first) set_next(t + 1);           // entry t + 1 was published an epilogue and several barriers ago
         bar();
         // phase 2: a1 x b1
         read_b(fb1, buf, 1);
@@ -465,19 +532,29 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         bar();
         // phase 3: a0 x b1
         stage_a(ca, buf, 0);
-        wait_vm<4>();                         // the whole next k-tile has landed
+        if (first && t > 0) wait_vm<4 + NSTORE>();   // the whole next k-tile has landed; the stores may still be out
+        else wait_vm<4>();
         bar();
+        P8_STAMP();
         mma0(fb1, 1);
-        if (last && wr == 1) epilogue();
+        if (last && wr == 1) {
+            stage_next(buf);
+            epilogue();
+        }
         bar();
-        if (last && wr == 0) epilogue();
+        if (last && wr == 0) {
+            draw();
+            stage_next(buf);
+            epilogue();
+        }
+        if (!last) stage_next(buf);
     };
     int kt = 0;
     for (;;) {
-        ktile(0, false);
+        ktile(0, kt == 0, false);
         kt += 2;
         const bool last = kt == KT;
-        ktile(1, last);
+        ktile(1, false, last);
         if (last) {
             kt = 0;
             t++;
@@ -487,6 +564,11 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     }
     if (wr == 0) bar();
     wait_vm<0>();
+#ifdef P8_LAB_TRACE
+    if ((tid & 255) == 0 && blockIdx.x == P8_LAB_TRACE)
+        for (int i = 0; i < 256; i++)
+            p8_trace[tid >> 8][i] = i < tr_n ? reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 8192)[(tid >> 8) * 256 + i] : 0ull;
+#endif
     finish();
 }
 
@@ -694,7 +776,11 @@ unsigned *queue_counters(hipStream_t s) {
 
 template <int NI, int MASK>
 int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
+#ifdef P8_LAB_TRACE
+    const int LDS_TOTAL = LDS_MAX;
+#else
     const int LDS_TOTAL = LDS_BIAS + (a.bias ? a.N * 2 : 0);
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>),
@@ -767,6 +853,8 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     if (a.a_kmajor || a.b_kmajor || splits != 1 || a.c_is_f32 || a.aux_out) return -1;
     if (a.act == SFCVIT_ACT_GELU || a.dact == SFCVIT_ACT_GELU) return -1;
     if (a.N % 256 || a.K % 128 || a.K < 256 || a.lda % 8 || a.ldb % 8 || a.ldc % 8) return -1;
+    if (a.lda >= (1 << 21) || a.ldb >= (1 << 21)) return -1;       // 32-bit byte offsets within a tile
+    if (a.M / 224 >= 32768 || a.N / 256 >= 65536) return -1;       // (row tile, column tile) packed into one int
     if (a.residual && (a.ldr % 8 || (reinterpret_cast<uintptr_t>(a.residual) & 15))) return -1;
     if (a.dact && (a.ldaux % 8 || (reinterpret_cast<uintptr_t>(a.aux_in) & 15))) return -1;
     if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return -1;
@@ -810,3 +898,9 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
 }
 
 }  // namespace sfcvit
+
+#ifdef P8_LAB_TRACE
+extern "C" int sfcvit_lab_trace(unsigned long long *host) {
+    return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(sfcvit::p8::p8_trace), sizeof(unsigned long long) * 512));
+}
+#endif
