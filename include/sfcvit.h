@@ -137,8 +137,8 @@ typedef struct sfcvit_gemm_args {
     int32_t force_generic; /* kernel choice, for tests and benchmarks: 0 = automatic (persistent 8-phase kernel when
                               both operands are k-contiguous and the shape sits on its tile grid, else the LDS-DMA
                               ring kernel, else the generic 128 x 128 kernel); 1 = generic only; 4 / 6 / 7 = ring
-                              kernel (heuristic / 256 x 128 / 256 x 256); 8 / 9 = persistent kernel with 256- /
-                              224-row tiles (EINVAL when not eligible) */
+                              kernel (heuristic / 256 x 128 / 256 x 256); 8 / 9 / 10 = persistent kernel with
+                              256- / 224- / 192-row tiles (EINVAL when not eligible) */
     float dropout_p;       /* > 0: after act, before residual: v = keep(m, n) ? v / (1 - p) : 0 (nn.Dropout, training) */
     uint32_t dropout_seed;
     float dact_scale;      /* multiplies v together with dact (0 = 1): 1/(1-p) of a dropout that followed the ReLU */

@@ -125,7 +125,7 @@ extern "C" int64_t sfcvit_gemm_workspace(int M, int N, int splitk) {
 
 extern "C" int64_t sfcvit_gemm_colsum_workspace(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    const int64_t fused = (int64_t(M) / 112 + 2) * N * int64_t(sizeof(float));      // partial rows of the 8-phase epilogue
+    const int64_t fused = (int64_t(M) / 96 + 2) * N * int64_t(sizeof(float));       // partial rows of the 8-phase epilogue (192-row tiles)
     const int64_t separate = sfcvit_colsum_workspace(M, N);
     return fused > separate ? fused : separate;
 }
@@ -181,7 +181,7 @@ static int gemm_impl(const sfcvit_gemm_args *a, void *stream) {
     }
 
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a->force_generic == 0 || a->force_generic == 8 || a->force_generic == 9) {
+    if (a->force_generic == 0 || (a->force_generic >= 8 && a->force_generic <= 10)) {
         int p8 = gemm8p_dispatch(*a, splits, s);
         if (p8 >= 0) return p8;
         int used = 0;

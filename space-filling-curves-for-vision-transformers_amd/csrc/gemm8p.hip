@@ -262,12 +262,12 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
 
     // --- staging: this thread's two 16-byte pieces of a half-tile (LDS rows r1 and r1 + 64) ---
     //   A0: LDS row 64 grp + w  <-  tile row grp*GR + w            (w < 64: fragments 0-3 of wave group grp)
-    //   A1: LDS row 64 grp + w  <-  tile row grp*GR + 64 + w       (w < GR - 64; NI = 7: rows 48..63 copy 32..47, never read)
+    //   A1: LDS row 64 grp + w  <-  tile row grp*GR + 64 + w       (w < GR - 64; the other rows of the slot copy earlier ones, never read)
     //   Bh: LDS row 32 wc + 16 jj + l  <-  column 64 wc + 16 (l >> 2) + 4 (2h + jj) + (l & 3): fragment order, so that a
     //       lane's accumulators are 16 consecutive columns
     const int r1 = 8 * wid + (lane >> 3);
     const int sc = (lane & 7) ^ ((r1 >> 1) & 7);                 // source chunk that lands in LDS chunk lane & 7
-    const int w1 = (r1 < GR - 64) ? r1 : r1 - 16;
+    const int w1 = (r1 < GR - 64) ? r1 : r1 - (NI == 7 ? 16 : 32);   // NI = 6: rows 32..63 copy 0..31
     const int b_row = (r1 >> 5) * 64 + ((r1 & 15) >> 2) * 16 + ((r1 >> 4) & 1) * 4 + (r1 & 3);
     // per-thread byte offsets (32 bits: the dispatcher bounds 256 rows x ld), added to wave-uniform bases so that the
     // LDS-DMA takes its scalar-base + 32-bit-offset form: three offset registers and no 64-bit vector adds in the loop
@@ -854,7 +854,7 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     if (a.act == SFCVIT_ACT_GELU || a.dact == SFCVIT_ACT_GELU) return -1;
     if (a.N % 256 || a.K % 128 || a.K < 256 || a.lda % 8 || a.ldb % 8 || a.ldc % 8) return -1;
     if (a.lda >= (1 << 21) || a.ldb >= (1 << 21)) return -1;       // 32-bit byte offsets within a tile
-    if (a.M / 224 >= 32768 || a.N / 256 >= 65536) return -1;       // (row tile, column tile) packed into one int
+    if (a.M / 192 >= 32768 || a.N / 256 >= 65536) return -1;       // (row tile, column tile) packed into one int
     if (a.residual && (a.ldr % 8 || (reinterpret_cast<uintptr_t>(a.residual) & 15))) return -1;
     if (a.dact && (a.ldaux % 8 || (reinterpret_cast<uintptr_t>(a.aux_in) & 15))) return -1;
     if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return -1;
@@ -878,7 +878,7 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     const int nt = a.N / 256;
     long best = -1;
     int ni = 0;
-    for (int cand : {8, 7}) {
+    for (int cand : {8, 7, 6}) {
         if (a.M % (32 * cand)) continue;
         const long tiles = long(a.M / (32 * cand)) * nt;
         const long cost = ((tiles + cus - 1) / cus) * cand;
@@ -887,11 +887,12 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     if (!ni) return -1;
     if (a.force_generic == 8) ni = (a.M % 256 == 0) ? 8 : ni;          // tests: pin the 256-row tile
     if (a.force_generic == 9) { if (a.M % 224) return -1; ni = 7; }    // tests: pin the 224-row tile
+    if (a.force_generic == 10) { if (a.M % 192) return -1; ni = 6; }   // tests: pin the 192-row tile
     if (mask & CSUM) {
         const int64_t need = int64_t(a.M / (16 * ni)) * a.N * int64_t(sizeof(float));
         if (!a.workspace || a.workspace_bytes < need || (reinterpret_cast<uintptr_t>(a.workspace) & 15)) return -1;
     }
-    const int rc = ni == 8 ? launch_mask<8>(a, mask, cus, s) : launch_mask<7>(a, mask, cus, s);
+    const int rc = ni == 8 ? launch_mask<8>(a, mask, cus, s) : ni == 7 ? launch_mask<7>(a, mask, cus, s) : launch_mask<6>(a, mask, cus, s);
     if (rc == 0 && (mask & CSUM))
         return launch_colsum_reduce(static_cast<const float *>(a.workspace), a.M / (16 * ni), a.N, a.colsum_out, a.colsum_bf16, s);
     return rc;

@@ -320,6 +320,8 @@ def test_gemm_row_slices_share_one_dropout_mask(ops):
     (256 * 37, 256 * 7, 256, 8),     # 259 tiles for 256 workgroups: some draw a third tile, short k loop
     (224 * 40, 256 * 7, 256, 9),     # 280 tiles
     (256 * 12, 768, 768, 8),         # ViT-B k loop
+    (192, 256, 256, 10),             # one 192-row tile
+    (192 * 41, 1024, 1024, 10),      # ViT-L out-projection shape, 164 tiles
 ])
 def test_gemm_persistent_kernel_against_fp32_and_generic(ops, M, N, K, mode):
     g = torch.Generator(device="cuda").manual_seed(21)
@@ -332,7 +334,7 @@ def test_gemm_persistent_kernel_against_fp32_and_generic(ops, M, N, K, mode):
     assert torch.equal(ops.gemm(a, w, force_generic=mode), ops.gemm(a, w, force_generic=1))
 
 
-@pytest.mark.parametrize("mode,M", [(8, 1024), (9, 896)])
+@pytest.mark.parametrize("mode,M", [(8, 1024), (9, 896), (10, 768)])
 def test_gemm_persistent_kernel_epilogues(ops, mode, M):
     """Every epilogue variant the persistent kernel is built for gives bit-identical results to the generic kernel
     (same fp32 accumulation order per k-tile is not guaranteed in general, so first compare against fp32 math)."""
