@@ -1,8 +1,8 @@
 // Persistent 8-phase bf16 MFMA GEMM for gfx950: C[M,N] = epilogue(A[M,K] B[N,K]^T), both operands
 // k-contiguous -- every forward GEMM of the encoder and (on the per-step transposed weight) every dX GEMM.
 //
-//   * tile (32*NI) x 256 x 64 with NI = 8 or 7 (256 or 224 rows: the height that wastes least of the last round
-//     of tiles on 256 CUs; M = 50176 = 196 * 256 = 224 * 224), 8 waves = 2 wave groups (row halves) x 4 column
+//   * tile (32*NI) x 256 x 64 with NI = 8, 7 or 6 (256, 224 or 192 rows: the height that wastes least of the last
+//     round of tiles on 256 CUs; M = 50176 = 196 * 256 = 224 * 224, ViT-L's 36864 = 192 * 192), 8 waves = 2 wave groups (row halves) x 4 column
 //     blocks, wave tile (16*NI) x 64, 16x16x32 MFMA.
 //   * one workgroup per CU walks output tiles that it draws from a per-XCD atomic counter (tiles are dealt to the XCDs
 //     in chunks of 32 consecutive ones, so the workgroups of an XCD share A row panels in its L2).  Drawing instead of
@@ -19,19 +19,22 @@
 //     half-tiles of a k-tile are cut so that each is read in exactly ONE phase -- A0 / A1 = the first 64 / the
 //     remaining rows of BOTH wave groups, B0 / B1 = the first / second 32 columns of ALL four column blocks:
 //         phase   reads (LDS)      MFMA (rows x cols)   LDS-DMA issued          counted wait before the barrier
-//           0     A0, B0           a0 x b0              A1 of k-tile g+1        -
-//           1     A1               a1 x b0              B1 of k-tile g+1        -
+//           0     A0, B0           a0 x b0              -                       -
+//           1     A1               a1 x b0              -                       -
 //           2     B1               a1 x b1              B0 of k-tile g+2        -
 //           3     -                a0 x b1              A0 of k-tile g+2        vmcnt(4): all of k-tile g+1
+//          end    -                -                    A1, B1 of k-tile g+2    -
+//     ("end" = after the phase-3 MFMAs; at the last k-tile of a tile that is before the epilogue, so that everything
+//     the next tile's first wait needs is older than the epilogue's stores: that wait is vmcnt(4 + stores).)
 //     Every half-tile is overwritten at least two phases after its only read, so no early retirement of LDS reads is
-//     needed; two to four half-tiles (32-64 KiB per CU) are in flight at any time; a buffer is read in the phases
+//     needed; four to six half-tiles (64-96 KiB per CU) are in flight at any time; a buffer is read in the phases
 //     after the wait that retires it.
 //   * LDS image of a half-tile: [128 rows][64 k] bf16, 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7)
 //     (ds_read_b128 conflict-free, tools/lds_conflicts.py); LDS-DMA writes are lane-linear, so the swizzle is
 //     applied to the per-lane SOURCE address.  B rows are stored in fragment order: LDS row 16j + l holds column
 //     16(l >> 2) + 4j + (l & 3) of the wave's 64, which makes the accumulators of a lane 16 CONSECUTIVE columns of
-//     one row -- the epilogue reads bias / residual / aux and writes C as 16-byte vectors straight from registers,
-//     no LDS transpose.
+//     one row -- the epilogue reads residual / aux as 16-byte vectors into the fragment layout; the packed result
+//     rows then pass through a wave-private LDS patch so that every store instruction is row-contiguous.
 //   * epilogue variants are compile-time (MASK) so that the fully unrolled per-row code stays small (DESIGN.md §5:
 //     the instruction cache punished a runtime option tree).  Wave group 1 runs its epilogue before, group 0 after
 //     the tile's last barrier: both run concurrently instead of one after the other.
