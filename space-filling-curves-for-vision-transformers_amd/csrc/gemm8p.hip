@@ -188,8 +188,14 @@ __device__ unsigned long long p8_trace[2][256];
             reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 8192)[(tid >> 8) * 256 + tr_n] = __builtin_amdgcn_s_memtime(); \
         tr_n++;                                                                                                      \
     } while (0)
+#ifdef P8_LAB_TRACE_PHASE   // also one stamp after the first barrier of phases 0-2
+#define P8_STAMP_PHASE() P8_STAMP()
+#else
+#define P8_STAMP_PHASE()
+#endif
 #else
 #define P8_STAMP()
+#define P8_STAMP_PHASE()
 #endif
 
 template <int NI, int MASK>
@@ -516,12 +522,14 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         read_b(fb0, buf, 0);
         read_a0(buf);
         bar();
+        P8_STAMP_PHASE();
         wait_lgkm<0>();
         mma0(fb0, 0);
         bar();
         // phase 1: a1 x b0
         read_a1(buf);
         bar();
+        P8_STAMP_PHASE();
         wait_lgkm<0>();
         mma1(fb0, 0);
         if (first) set_next(t + 1);           // entry t + 1 was published an epilogue and several barriers ago
@@ -530,6 +538,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         read_b(fb1, buf, 1);
         stage_b(cb, buf, 0);
         bar();
+        P8_STAMP_PHASE();
         wait_lgkm<0>();
         mma1(fb1, 1);
         bar();
