@@ -169,6 +169,9 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
 #ifdef P8_LAB_NOSTORE2     // lab builds only: everything but the global store instructions (results are wrong)
     if (g.M > 0) { asm volatile("" ::"v"(w0), "v"(w1)); return; }
 #endif
+#ifdef P8_LAB_NOSTORE_WG   // lab builds only: workgroup P8_LAB_NOSTORE_WG alone (> 0) / all but workgroup -P8_LAB_NOSTORE_WG skip the stores
+    if ((P8_LAB_NOSTORE_WG > 0) == (int(blockIdx.x) == (P8_LAB_NOSTORE_WG > 0 ? P8_LAB_NOSTORE_WG : -(P8_LAB_NOSTORE_WG)))) { asm volatile("" ::"v"(w0), "v"(w1)); return; }
+#endif
 #ifdef P8_LAB_STORE_HALF   // lab builds only: the same number of store instructions, half the bytes (results are wrong)
     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_lab;
     *reinterpret_cast<u32x2_lab *>(c) = u32x2_lab{w0[0], w0[1]};
