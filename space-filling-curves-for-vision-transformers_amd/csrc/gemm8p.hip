@@ -178,8 +178,19 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
     *reinterpret_cast<u32x2_lab *>(c + size_t(8) * g.ldc) = u32x2_lab{w1[0], w1[1]};
     return;
 #endif
-    *reinterpret_cast<u32x4 *>(c) = w0;
-    *reinterpret_cast<u32x4 *>(c + size_t(8) * g.ldc) = w1;
+#ifdef P8_LAB_STORE_BITS   // lab builds only: cache-policy bits on the stores, e.g. -DP8_LAB_STORE_BITS='"sc0 sc1"'
+    asm volatile("global_store_dwordx4 %0, %1, off " P8_LAB_STORE_BITS ::"v"(c), "v"(w0) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off " P8_LAB_STORE_BITS ::"v"(c + size_t(8) * g.ldc), "v"(w1) : "memory");
+    return;
+#endif
+    // Streaming stores (system scope + non-temporal): C is far larger than the L2 and is next read by another kernel;
+    // written through, it does not push the B panel and the A rows the other workgroups are loading out of the L2
+    // (measured with the cache-policy bits one by one, same process: plain 181 / 246 / 227 us for QKV / FFN1 / FFN2
+    // forward, `nt` 170 / 226 / 219, `sc0 sc1 nt` 170 / 219 / 215).  From asm because the builtin only has `nt`;
+    // s_nop: the store-data hazard (a VALU write of these registers right behind a wide store) is hipcc's to pad
+    // only for stores it emitted itself.
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(c), "v"(w0) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(c + size_t(8) * g.ldc), "v"(w1) : "memory");
 #endif
 }
 
