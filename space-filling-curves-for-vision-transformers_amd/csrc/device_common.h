@@ -22,8 +22,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(uint16_t, h);
 }
+// Two at once: the vector conversion is ONE v_cvt_pk_bf16_f32; two scalar casts + shift + or compiled to two of them
+// (each with a dummy second operand) plus three fix-up instructions per pair.
+typedef __attribute__((ext_vector_type(2))) float f32x2_cvt;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_cvt;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return uint32_t(f2bf(lo)) | (uint32_t(f2bf(hi)) << 16);
+    const f32x2_cvt v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_cvt));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
