@@ -50,6 +50,11 @@ __device__ __forceinline__ bf16x4 pack_frag4(const f32x4 &a) {
 constexpr int WAVES = THREADS / 64;
 constexpr int MAXOWN = MAXF / WAVES;   // fragments a wave owns at most (4)
 
+// NFC = the number of 16-row fragments as a compile-time constant (0 = take it from N at run time).  With it the
+// per-fragment `kf < nf` tests of the fully unrolled score row and the chunk loops fold away -- for the generic version
+// hipcc emits ~250 branches around the forward kernel's MFMAs, each one a scheduling barrier.  ViT-B/16 @ 224
+// (N = 196) runs the 13-fragment instances.
+template <int NFC>
 __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_attn_args a, int npad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *kimg = smem, *vimg = smem + npad * 128;
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_a
     const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
     const uint16_t *qp = base, *kp = base + D, *vp = base + 2 * D;
     uint16_t *out = static_cast<uint16_t *>(a.out) + size_t(b) * N * D + h * HD;
-    const int nf = (N + 15) >> 4, nc = npad >> 5;        // npad = 16 nf; nc full 32-key chunks (+ a 16-key tail if nf is odd)
+    const int nf = NFC ? NFC : (N + 15) >> 4, nc = NFC ? (NFC >> 1) : npad >> 5;   // npad = 16 nf; nc full 32-key chunks (+ a 16-key tail if nf is odd)
     // This wave's query fragments, fetched before the K/V staging so that their HBM latency is
     // hidden behind it (fragment index = wave + 4*o).
     bf16x8 qfr[MAXOWN][2];
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_a
 }
 
 // dK, dV: waves own 16-key fragments; Q and dO of the whole sequence are in LDS.
+template <int NFC>
 __global__ __launch_bounds__(THREADS, 2) void attn_seq_bwd_kv_kernel(const sfcvit_attn_args a, int npad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *qimg = smem, *doimg = smem + npad * 128;
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_bwd_kv_kernel(const sfcvi
         rkey_s[i] = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(i));
     }
     __syncthreads();
-    const int nf = (N + 15) >> 4, nc = npad >> 5;
+    const int nf = NFC ? NFC : (N + 15) >> 4, nc = NFC ? ((NFC + 1) >> 1) : npad >> 5;   // npad = 32 nc here
     const float scale = a.scale, c2 = a.scale * 1.4426950408889634f;
     const LaneOff lo = lane_offsets(lane);
     const bool drop = a.dropout_p > 0.f;
@@ -239,6 +245,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_bwd_kv_kernel(const sfcvi
 }
 
 // dQ: waves own 16-query fragments; K and V of the whole sequence are in LDS.
+template <int NFC>
 __global__ __launch_bounds__(THREADS, 3) void attn_seq_bwd_q_kernel(const sfcvit_attn_args a, int npad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *kimg = smem, *vimg = smem + npad * 128;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_bwd_q_kernel(const sfcvit
     dma_seq<false>(kimg, kp, ld, N, npad, tid);
     dma_seq<false>(vimg, vp, ld, N, npad, tid);
     __syncthreads();
-    const int nf = (N + 15) >> 4, nc = npad >> 5;
+    const int nf = NFC ? NFC : (N + 15) >> 4, nc = NFC ? (NFC >> 1) : npad >> 5;
     const float scale = a.scale, c2 = a.scale * 1.4426950408889634f;
     const LaneOff lo = lane_offsets(lane);
     const bool drop = a.dropout_p > 0.f;
@@ -326,8 +333,9 @@ constexpr int SEQ_MAX_LDS = 2 * SEQ_MAX_N * 128 + 3 * SEQ_MAX_N * 4;
 int set_lds_limit() {
     static bool done = false;
     if (done) return SFCVIT_OK;
-    for (const void *k : {reinterpret_cast<const void *>(&attn_seq_fwd_kernel), reinterpret_cast<const void *>(&attn_seq_bwd_kv_kernel),
-                          reinterpret_cast<const void *>(&attn_seq_bwd_q_kernel)})
+    for (const void *k : {reinterpret_cast<const void *>(&attn_seq_fwd_kernel<0>), reinterpret_cast<const void *>(&attn_seq_bwd_kv_kernel<0>),
+                          reinterpret_cast<const void *>(&attn_seq_bwd_q_kernel<0>), reinterpret_cast<const void *>(&attn_seq_fwd_kernel<13>),
+                          reinterpret_cast<const void *>(&attn_seq_bwd_kv_kernel<13>), reinterpret_cast<const void *>(&attn_seq_bwd_q_kernel<13>)})
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_MAX_LDS) != hipSuccess)
             return check_launch("attention_seq attribute");
     done = true;
@@ -340,7 +348,8 @@ int attn_seq_fwd(const sfcvit_attn_args &a, hipStream_t s) {
     if (a.N > SEQ_MAX_N) return -1;
     if (int rc = set_lds_limit()) return rc;
     const int npad = (a.N + 15) / 16 * 16;
-    hipLaunchKernelGGL(attn_seq_fwd_kernel, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128), s, a, npad);
+    if ((a.N + 15) / 16 == 13) hipLaunchKernelGGL(attn_seq_fwd_kernel<13>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128), s, a, npad);
+    else hipLaunchKernelGGL(attn_seq_fwd_kernel<0>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128), s, a, npad);
     return check_launch("attention_seq_fwd");
 }
 
@@ -348,10 +357,13 @@ int attn_seq_bwd(const sfcvit_attn_args &a, hipStream_t s) {
     if (a.N > SEQ_MAX_N) return -1;
     if (int rc = set_lds_limit()) return rc;
     const int npad = (a.N + 31) / 32 * 32;
-    hipLaunchKernelGGL(attn_seq_bwd_kv_kernel, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128 + 3 * npad * 4), s, a, npad);
+    const bool nf13 = (a.N + 15) / 16 == 13;
+    if (nf13) hipLaunchKernelGGL(attn_seq_bwd_kv_kernel<13>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128 + 3 * npad * 4), s, a, npad);
+    else hipLaunchKernelGGL(attn_seq_bwd_kv_kernel<0>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128 + 3 * npad * 4), s, a, npad);
     if (int rc = check_launch("attention_seq_bwd kv")) return rc;
     const int npad16 = (a.N + 15) / 16 * 16;
-    hipLaunchKernelGGL(attn_seq_bwd_q_kernel, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad16 * 128), s, a, npad16);
+    if (nf13) hipLaunchKernelGGL(attn_seq_bwd_q_kernel<13>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad16 * 128), s, a, npad16);
+    else hipLaunchKernelGGL(attn_seq_bwd_q_kernel<0>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad16 * 128), s, a, npad16);
     return check_launch("attention_seq_bwd q");
 }
 
