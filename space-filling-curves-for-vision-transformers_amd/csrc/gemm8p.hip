@@ -103,7 +103,7 @@ struct StoreMap {
 template <int MASK>
 __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, int n, float (&v)[16], const float (&bv)[16],
                                              const u32x4 (&side)[2], uint32_t thresh, float keep_scale, float dact_scale,
-                                             const StoreMap &sm) {
+                                             const StoreMap &sm, uint32_t rk_in0, uint32_t rk_in1) {
     if (!(MASK & DACT)) {                                       // gradient GEMMs carry no bias (the dispatcher checks)
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] += bv[r];
@@ -113,7 +113,10 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
         for (int r = 0; r < 16; r++) v[r] = fmaxf(v[r], 0.f);
     }
     if (MASK & DROP) {
-        const uint32_t rk = drop_row_key(g.dropout_seed, uint64_t(m) + uint64_t(uint32_t(g.row_offset)));
+        // drop_row_key(seed, row) with its inner hash (a function of the seed and of row >> 32, which is 0 or 1 here:
+        // m < 2^31, row_offset < 2^32) taken from the two wave-uniform values worked out once per kernel
+        const uint64_t row = uint64_t(m) + uint64_t(uint32_t(g.row_offset));
+        const uint32_t rk = mix32(uint32_t(row) * 0x9E3779B1u + ((row >> 32) ? rk_in1 : rk_in0));
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             bool k0, k1;
@@ -407,6 +410,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
 
     const uint32_t thresh = (MASK & DROP) ? drop_thresh(g.dropout_p) : 0u;
     const float keep_scale = (MASK & DROP) ? 1.f / (1.f - g.dropout_p) : 1.f;
+    const uint32_t rk_in0 = (MASK & DROP) ? mix32(g.dropout_seed) : 0u, rk_in1 = (MASK & DROP) ? mix32(g.dropout_seed ^ 0x7FEB352Du) : 0u;
     const float dact_scale = g.dact_scale != 0.f ? g.dact_scale : 1.f;
     auto draw = [&]() __attribute__((always_inline)) {        // wave group 0, before its epilogue (tid 0 is in it)
         if (tid == 0) {
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
                 float v[16] = {acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3], acc[i][1][0], acc[i][1][1],
                                acc[i][1][2], acc[i][1][3], acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3],
                                acc[i][3][0], acc[i][3][1], acc[i][3][2], acc[i][3][3]};
-                epilogue_row<MASK>(g, m0 + 16 * i, n0, v, bv, side[i - i0], thresh, keep_scale, dact_scale, sm);
+                epilogue_row<MASK>(g, m0 + 16 * i, n0, v, bv, side[i - i0], thresh, keep_scale, dact_scale, sm, rk_in0, rk_in1);
                 if (MASK & CSUM) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) cs[r] += v[r];      // the fp32 values that were just stored as bf16
