@@ -567,17 +567,21 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         bar();
         P8_STAMP();
         mma0(fb1, 1);
-        if (last && wr == 1) {
+        // ONE copy of the epilogue code (group 1 runs it before, group 0 after the tile's last barrier), so that the
+        // other k-tiles branch over it once, not twice: a taken branch across ~5 KB of code costs ~100 clocks
+        // (measured with P8_LAB_TRACE: the k-tile pairs that contained the two jumps were 300 clocks longer)
+        if (last) {
+            if (wr == 0) {
+                bar();
+                draw();
+            }
             stage_next(buf);
             epilogue();
-        }
-        bar();
-        if (last && wr == 0) {
-            draw();
+            if (wr == 1) bar();
+        } else {
+            bar();
             stage_next(buf);
-            epilogue();
         }
-        if (!last) stage_next(buf);
     };
     int kt = 0;
     for (;;) {
