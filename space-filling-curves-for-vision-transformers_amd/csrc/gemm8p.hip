@@ -516,14 +516,12 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     // One k-tile g in buffer `buf`.  On entry k-tile g+1 is issued in full and `ca` / `cb` are k-tile g+2.
     // One counted wait per k-tile (phase 3, vmcnt(4): everything but the two half-tiles issued last has landed, i.e.
     // the whole next k-tile).  Waiting per half-tile just before its first use (vmcnt(8) in phases 0, 1 and 3) measured
-    // 2-5 % slower in the same process; it also keeps the epilogue's stores -- vector-memory operations that retire
-    // in order with the LDS-DMA -- three phases away from the next wait.  Also measured and not kept: issuing each
+    // 2-5 % slower in the same process.  Also measured and not kept: issuing each
     // phase's fragment reads one phase early, under the previous phase's MFMAs (role-swapping register sets): no
     // gain (1051 / 813 / 977 / 1073 vs 1043 / 819 / 985 / 1116 TFLOP/s on the four forward shapes) and spills at
     // 256 registers -- LDS read latency is not what the load section of a phase waits for.
     // Tile boundary.  Vector-memory operations retire in order, so a counted wait right after an epilogue also waits
-    // for the epilogue's stores to be acknowledged -- measured: as long as two to three k-tiles on a busy L2, with
-    // the MFMAs idle meanwhile.  Therefore A1 / B1 of k-tile g+2 are issued at the END of k-tile g (both groups are
+    // for the epilogue's stores to be acknowledged.  Therefore A1 / B1 of k-tile g+2 are issued at the END of k-tile g (both groups are
     // through with these halves by then), which at a tile boundary is before the epilogue: everything the first
     // k-tile of the next tile waits for is older than the stores, and its wait can leave them outstanding --
     // vmcnt(4 + NSTORE).  The next wait is a whole k-tile later.
