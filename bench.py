@@ -4,19 +4,33 @@
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --cpu-only                      # BASELINE config 1: ViT-Tiny raster, batch 32, host cores only
 
-Workload (BASELINE.json configs[2] / [3]): ViT-B/16 at 224x224, Hilbert pixel order
+Default workload (BASELINE.json configs[2] / [3]): ViT-B/16 at 224x224, Hilbert pixel order
 (HilbertEmbedding1D(224, 256, 3, 768) + VisionTransformer1D(depth 12, heads 12, mlp 3072,
 1000 classes)), 256 synthetic images per GPU, training mode with the reference's dropout
 (0.1 at the four encoder sites, 0.5 in the head), one full training step = zero_grad ->
 forward -> soft-target CE -> backward -> (gradient all-reduce) -> clip 1.0 -> AdamW.
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline`
-(the dominant kernel, timed live with HIP events) and `cpu_baseline` (the oracle's
-fp32 PyTorch-CPU restatement timed on the host cores, rank 0 at N = 1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement).
+
+What the line's roofline numbers are, so that they can be recomputed from profiles/ alone:
+  * `roofline`      the dominant kernel FAMILY of the step: all instantiations of the persistent 8-phase GEMM
+                    `gemm8p_kernel<NI, MASK>` (every forward and dX GEMM).  achieved = sum of 2MNK over the family's
+                    launches in the timed region / sum of their HIP-event durations (events on the launching stream);
+                    peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).  `traffic` = launch-weighted mean of the
+                    family's HBM-side bytes per launch from the PMC passes in profiles/traffic.json for THIS workload
+                    (null when the workload has no PMC pass); `algorithmic_bytes` beside it.
+  * `roofline_detail`  the same quantity for: every GEMM symbol, the worst GEMM, the weight-gradient kernel
+                    (`gemm8p_km_kernel`), attention forward / backward (both bounds: FLOP/s of 2.5 PF and algorithmic
+                    bytes/s of 8 TB/s -- at N = 196, hd = 64 attention is below the ridge, i.e. HBM-bound), the fused
+                    gather + patch-embed kernels (both bounds) and the whole step.
+  * `cpu_baseline`  the oracle's fp32 PyTorch-CPU restatement of the reference path timed on the host cores
+                    (rank 0 at N = 1 only): BASELINE.md §3 -- 1 warm-up + 3 timed steps, all cores of the box's share.
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -31,11 +45,15 @@ PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, MI355X_MICROARCH.md "Chip-leve
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
-    # name: (img, patch_px, D, depth, heads, mlp, classes, per-GPU batch)
-    "vit_b16_224_hilbert": (224, 256, 768, 12, 12, 3072, 1000, 256),
-    "vit_tiny16_32_hilbert": (32, 256, 192, 12, 3, 768, 10, 256),
-    "vit_l16_384_hilbert": (384, 256, 1024, 24, 16, 4096, 1000, 64),
+    # name: (tokenizer, img, pixels per token, D, depth, heads, mlp, classes, per-GPU batch, CPU-baseline batch)
+    "vit_b16_224_hilbert": ("hilbert", 224, 256, 768, 12, 12, 3072, 1000, 256, 32),      # BASELINE configs 3, 4
+    "vit_tiny16_32_hilbert": ("hilbert", 32, 256, 192, 12, 3, 768, 10, 256, 256),         # config 2
+    "vit_tiny16_32_raster": ("raster", 32, 256, 192, 12, 3, 768, 10, 32, 32),             # config 1 (CPU plumbing case)
+    "vit_l16_384_hilbert": ("hilbert", 384, 256, 1024, 24, 16, 4096, 1000, 64, 8),        # config 5, three orders
+    "vit_l16_384_z": ("z", 384, 256, 1024, 24, 16, 4096, 1000, 64, 8),
+    "vit_l16_384_raster": ("raster", 384, 256, 1024, 24, 16, 4096, 1000, 64, 8),
 }
+ORDER_NAME = {"hilbert": "Hilbert", "z": "Z (Morton)", "raster": "raster"}
 
 
 def train_flops_per_image(img, patch, D, depth, heads, F, classes):
@@ -48,23 +66,58 @@ def train_flops_per_image(img, patch, D, depth, heads, F, classes):
 
 def build(workload, dropout):
     from sfcvit.models import VisionTransformer1D
-    from sfcvit.tokenizers import HilbertEmbedding1D
-    img, patch, D, depth, heads, mlp, classes, _ = WORKLOADS[workload]
+    from sfcvit.tokenizers import HilbertEmbedding1D, MortonEmbedding1D, RasterScan1DEmbedding
+    tok, img, patch, D, depth, heads, mlp, classes, _, _ = WORKLOADS[workload]
     torch.manual_seed(42)                                   # main.py:151-152
-    pe = HilbertEmbedding1D(img, patch, 3, D)
+    cls = {"hilbert": HilbertEmbedding1D, "z": MortonEmbedding1D, "raster": RasterScan1DEmbedding}[tok]
+    pe = cls(img, patch, 3, D)
     model = VisionTransformer1D(pe, depth=depth, n_heads=heads, mlp_dim=mlp, num_classes=classes,
                                 dropout_p=dropout, head_dropout_p=0.5 if dropout > 0 else 0.0)
     return model
 
 
-def cpu_baseline(workload, batch, steps):
+def host_cores():
+    """Cores this process may use: the affinity mask, capped by the cgroup CPU quota (the GPU box gives a one-GPU job a
+    16-core share of a larger host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, quota // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload, batch, steps, cores=None):
     """The oracle (fp32 PyTorch-CPU restatement of the reference path) on the host cores: full
     train step (fwd + soft-target CE + bwd + clip + AdamW), same synthetic input definition."""
     from oracle import vit_oracle
-    img, patch, D, depth, heads, mlp, classes, _ = WORKLOADS[workload]
-    cores = min(16, os.cpu_count() or 1)
+    tok, img, patch, D, depth, heads, mlp, classes, _, _ = WORKLOADS[workload]
+    cores = cores or host_cores()
     torch.set_num_threads(cores)
-    cfg = vit_oracle.OracleConfig("hilbert1d", img, patch, 3, D, depth, heads, mlp, classes, "1d")
+    kind = {"hilbert": "hilbert1d", "z": "morton1d", "raster": "raster1d"}[tok]
+    cfg = vit_oracle.OracleConfig(kind, img, patch, 3, D, depth, heads, mlp, classes, "1d")
     sd = vit_oracle.random_state(cfg, seed=42)
     leaves = [v.requires_grad_(True) for k, v in vit_oracle.trainable(sd).items()
               if not k.startswith(vit_oracle.UNUSED_PREFIXES)]
@@ -79,9 +132,36 @@ def cpu_baseline(workload, batch, steps):
     for _ in range(steps):
         vit_oracle.train_step(x, tgt, sd, cfg, opt)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
+    flops = train_flops_per_image(img, patch, D, depth, heads, mlp, classes)
+    return {"value": batch / dt, "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "ms_per_step": dt * 1e3, "achieved_gflops": batch / dt * flops / 1e9,
             "sample": f"{steps} train steps of batch {batch} (fp32, torch {torch.__version__} CPU, "
-                      f"{cores} threads) after 1 warm-up, same model and synthetic inputs"}
+                      f"{cores} threads) after 1 warm-up, same model and synthetic input definition"}
+
+
+def load_traffic(workload):
+    """profiles/traffic.json: {"workloads": {workload: {"kernels": {symbol: {"traffic_bytes": ...}}}}} -- per-launch
+    HBM-side bytes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/traffic_from_pmc.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            doc = json.load(f)
+        wl = doc.get("workloads", {}).get(workload)
+        return (wl or {}).get("kernels", {}), (wl or {}).get("build")
+    except (OSError, ValueError):
+        return {}, None
+
+
+def frac_entry(rec, bound_flops=True, bytes_per_launch=None):
+    """A roofline entry from a KernelTimer record (work_total = FLOPs)."""
+    sec = rec["ms_total"] * 1e-3
+    out = {"launches": rec["launches"], "avg_launch_ms": round(rec["ms_avg"], 4),
+           "tflops": round(rec["work_total"] / sec / 1e12, 1),
+           "mfma_frac": round(rec["work_total"] / sec / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    if bytes_per_launch is not None:
+        gbs = bytes_per_launch * rec["launches"] / sec / 1e9
+        out.update({"algorithmic_bytes": int(bytes_per_launch), "gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
+        out["bound"] = "hbm" if out["hbm_frac"] >= out["mfma_frac"] else "mfma"
+    return out
 
 
 def main():
@@ -89,19 +169,36 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="vit_b16_224_hilbert", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--dropout", type=float, default=0.1,
                     help="encoder dropout (reference default 0.1; the head then uses the reference's 0.5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true",
-                    help="HIP-event pairs around every op (default: only the GEMM families, the dominant kernels; "
-                         "700 event pairs per step cost ~2.5 %% of throughput)")
-    ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+                    help="HIP-event pairs around every op (default: GEMMs, attention and patch embed; ~740 event pairs "
+                         "per ViT-B step cost ~2.5 %% of throughput)")
+    ap.add_argument("--cpu-only", action="store_true",
+                    help="no GPU: time the CPU restatement only (default workload vit_tiny16_32_raster, BASELINE config 1)")
+    ap.add_argument("--cpu-batch", type=int, default=0, help="CPU-baseline batch (default: BASELINE.md §3's per workload)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="replay the whole training step from one hipGraph")
     args = ap.parse_args()
 
+    if args.cpu_only:
+        wl = args.workload or "vit_tiny16_32_raster"
+        tok, img, patch, D, depth, heads, mlp, classes, _, cbatch = WORKLOADS[wl]
+        base = cpu_baseline(wl, args.cpu_batch or cbatch, args.cpu_steps)
+        print(json.dumps({"metric": f"images/sec {wl} training (CPU reference path)", "value": round(base["value"], 2),
+                          "unit": "images/s", "n_gpus": 0, "steps": args.cpu_steps, "warmup": 1,
+                          "ms_per_step": round(base["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"{wl}: {img}x{img} {ORDER_NAME[tok]} pixel order, batch "
+                                                 f"{args.cpu_batch or cbatch}, full train step on the host cores"},
+                          "cpu_baseline": base}), flush=True)
+        return
+
+    args.workload = args.workload or "vit_b16_224_hilbert"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -118,12 +215,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, "process group size != --gpus"
 
     from sfcvit import ops
     from sfcvit.training import FusedAdamW, GradReducer, mixup_soft_targets, train_step
 
-    img, patch, D, depth, heads, mlp, classes, batch = WORKLOADS[args.workload]
+    tok, img, patch, D, depth, heads, mlp, classes, batch, cbatch = WORKLOADS[args.workload]
     batch = args.batch or batch
+    N = img * img // patch
     model = build(args.workload, args.dropout).to(dev, dtype=torch.bfloat16)
     model.train() if args.dropout > 0 else model.eval()    # eval() only switches dropout off; grads flow
     opt = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=5e-5, max_grad_norm=1.0)
@@ -139,14 +238,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = lambda: train_step(model, images, targets, opt, reducer=reducer)     # noqa: E731
+    if args.graph:
+        from sfcvit.training import GraphedTrainStep
+        if world > 1:
+            raise SystemExit("--graph: single-GPU only (the collectives are launched from autograd hooks)")
+        step = GraphedTrainStep(model, images, targets, opt, warmup=max(2, args.warmup))
+
     for _ in range(args.warmup):
-        loss = train_step(model, images, targets, opt, reducer=reducer)
-    if rank == 0 and not args.no_kernel_timing:
-        ops.TIMER = ops.KernelTimer(None if args.time_all_kernels else "gemm ")
+        loss = step()
+    timing = rank == 0 and not args.no_kernel_timing and not args.graph
+    if timing:
+        ops.TIMER = ops.KernelTimer(None if args.time_all_kernels else ("gemm ", "attn", "pe_"))
+    if reducer is not None:
+        reducer.reset_stats()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(model, images, targets, opt, reducer=reducer)
+        loss = step()
     sync()
     dt = time.perf_counter() - t0
     kern = ops.TIMER.summary() if ops.TIMER is not None else {}
@@ -169,39 +278,68 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {img}x{img} Hilbert pixel order, 16x16-pixel tokens, "
+            "config": {"workload": f"{args.workload}: {img}x{img} {ORDER_NAME[tok]} pixel order, 16x16-pixel tokens, "
                                    f"batch {batch}/GPU, full train step (fwd+CE+bwd+clip+AdamW)",
-                       "global_batch": world * batch, "parallelism": f"dp{world}", "dropout": args.dropout},
+                       "global_batch": world * batch, "parallelism": f"dp{world}", "dropout": args.dropout,
+                       "hip_graph": bool(args.graph)},
             "train_gflop_per_image": round(flops_img / 1e9, 3),
             "step_tflops_per_gpu": round(value / world * flops_img / 1e12, 2),
             "step_mfma_frac": round(value / world * flops_img / 1e12 / PEAK_BF16_TFLOPS, 4),
             "final_loss": round(loss_v, 4),
         }
+        if world > 1:
+            out["rccl"] = dict(reducer.stats(args.steps), backend=backend, world_size=dist.get_world_size())
         if kern:
+            traffic, traffic_build = load_traffic(args.workload)
             gemm_keys = [k for k in kern if k.startswith("gemm ")]
-            dom = max(kern, key=lambda k: kern[k]["ms_total"])
-            r = kern[dom]
-            ach = r["work_total"] / (r["ms_total"] * 1e-3) / 1e12
-            # GEMM timing keys are "gemm <kernel symbol>" (sfcvit_last_gemm_kernel): the name rocprofv3 shows for the
-            # same launches in profiles/ (there prefixed with the namespace).
-            symbol = dom[5:] if dom.startswith("gemm ") else dom
-            traffic = None                          # PMC counters cannot be read live: offline passes, see profiles/traffic.json
-            try:
-                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    traffic = json.load(f)["kernels"].get(symbol, {}).get("traffic_bytes")
-            except (OSError, ValueError, KeyError):
-                pass
-            out["roofline"] = {"kernel": dom, "rocprof_symbol": symbol, "bound": "mfma", "achieved": round(ach, 2),
-                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                               "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md)" if traffic else None,
-                               "launches": r["launches"], "avg_launch_ms": round(r["ms_avg"], 4),
-                               "flops_per_launch": r["work_total"] / r["launches"]}
-            out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": round(v["ms_total"] / args.steps, 3),
-                                  "tflops": round(v["work_total"] / (v["ms_total"] * 1e-3) / 1e12, 1)}
-                              for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_total"])}
-            out["gemm_ms_per_step"] = round(sum(kern[k]["ms_total"] for k in gemm_keys) / args.steps, 3)
+            fam = [k for k in gemm_keys if k.startswith("gemm gemm8p_kernel<")]
+            detail = {}
+            for k in gemm_keys:
+                detail[k[5:]] = frac_entry(kern[k])
+                t = traffic.get(k[5:], {}).get("traffic_bytes")
+                if t is not None:
+                    detail[k[5:]]["traffic"] = t
+            if fam:
+                tot = {"launches": sum(kern[k]["launches"] for k in fam), "ms_total": sum(kern[k]["ms_total"] for k in fam),
+                       "work_total": sum(kern[k]["work_total"] for k in fam)}
+                tot["ms_avg"] = tot["ms_total"] / tot["launches"]
+                ach = tot["work_total"] / (tot["ms_total"] * 1e-3) / 1e12
+                known = [k for k in fam if traffic.get(k[5:], {}).get("traffic_bytes") is not None]
+                tr = None
+                if known and len(known) == len(fam):
+                    tr = sum(traffic[k[5:]]["traffic_bytes"] * kern[k]["launches"] for k in fam) / tot["launches"]
+                out["roofline"] = {
+                    "kernel": "gemm8p_kernel<*> (persistent 8-phase GEMM: every forward and dX GEMM; all instantiations, flop-weighted)",
+                    "rocprof_symbol": "gemm8p_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": tr,
+                    "traffic_source": (f"profiles/traffic.json [{args.workload}] build {traffic_build}: rocprofv3 --pmc FETCH_SIZE / "
+                                       "WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md; launch-weighted mean over "
+                                       "the family") if tr is not None else None,
+                    "launches": tot["launches"], "avg_launch_ms": round(tot["ms_avg"], 4),
+                    "flops_per_launch": tot["work_total"] / tot["launches"], "ms_per_step": round(tot["ms_total"] / args.steps, 3)}
+                worst = min(fam, key=lambda k: kern[k]["work_total"] / kern[k]["ms_total"])
+                detail["worst_gemm"] = dict(detail[worst[5:]], kernel=worst[5:])
+            all_g = {"launches": sum(kern[k]["launches"] for k in gemm_keys), "ms_total": sum(kern[k]["ms_total"] for k in gemm_keys),
+                     "work_total": sum(kern[k]["work_total"] for k in gemm_keys)}
+            all_g["ms_avg"] = all_g["ms_total"] / max(1, all_g["launches"])
+            detail["all_gemms"] = frac_entry(all_g)
+            bh = batch * N
+            if "attn_fwd_kernel" in kern:
+                detail["attention_fwd"] = frac_entry(kern["attn_fwd_kernel"], bytes_per_launch=bh * 4 * D * 2 + batch * heads * N * 4)
+                detail["attention_fwd"]["ms_per_step"] = round(kern["attn_fwd_kernel"]["ms_total"] / args.steps, 3)
+            if "attn_bwd" in kern:        # algorithmic minimum: read qkv, o, do, lse; write dqkv
+                detail["attention_bwd"] = frac_entry(kern["attn_bwd"], bytes_per_launch=bh * 8 * D * 2 + batch * heads * N * 4)
+                detail["attention_bwd"]["ms_per_step"] = round(kern["attn_bwd"]["ms_total"] / args.steps, 3)
+            pe_in = batch * 3 * img * img * 4       # the fp32 image batch as the model receives it
+            if "pe_fwd_kernel" in kern:
+                detail["patch_embed_fwd"] = frac_entry(kern["pe_fwd_kernel"], bytes_per_launch=pe_in + bh * D * 2 + D * 3 * patch * 2)
+            if "pe_bwd_kernel" in kern:
+                detail["patch_embed_bwd"] = frac_entry(kern["pe_bwd_kernel"], bytes_per_launch=pe_in + bh * D * 2 + D * 3 * patch * 4)
+            detail["step"] = {"tflops": out["step_tflops_per_gpu"], "mfma_frac": out["step_mfma_frac"]}
+            out["roofline_detail"] = detail
+            out["gemm_ms_per_step"] = round(all_g["ms_total"] / args.steps, 3)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch or cbatch, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

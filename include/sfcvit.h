@@ -156,11 +156,6 @@ typedef struct sfcvit_gemm_args {
 int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);
 /* HOST: workspace bytes for a call with colsum_out. */
 int64_t sfcvit_gemm_colsum_workspace(int M, int N);
-/* Measurement helper (tools/bench_busy_cus.py): keeps n_wgs CUs busy for ~`cycles` shader cycles on `stream` with a
- * kernel whose LDS footprint (64 KiB) keeps the 8-phase GEMM off those CUs -- a stand-in for a collective running
- * beside backward.  `sink`: any 4 device bytes. */
-int sfcvit_test_occupy(int n_wgs, long long cycles, void *sink, void *stream);
-
 /* HOST: name of the kernel the calling thread's last sfcvit_gemm launched, as rocprofv3 prints it (without the
  * namespace), e.g. "gemm8p_kernel<7, 6>" -- lets a benchmark key its live timings by kernel symbol. */
 int sfcvit_last_gemm_kernel(char *buf, int n);

@@ -79,3 +79,33 @@ ALTVIT_CASES = {
     "simplevit32": ("SimpleViT", dict(image_size=32, patch_size=8, num_classes=7, dim=64, depth=1, heads=1, mlp_dim=128), 2),
     "hilbertvit64_p16": ("HilbertViT", dict(image_size=64, patch_size=16, num_classes=10, dim=192, depth=1, heads=3, mlp_dim=384), 2),
 }
+
+# ---- BASELINE.json configurations at their TRUE model dimensions (round 2) -----------------------------------
+# name -> (config, batch).  Fixtures: tests/golden/full_<name>.json (tools/make_golden_full.py; the reference's own
+# classes evaluated on formula weights: logits, loss, per-parameter gradient norms only -- nothing large is stored).
+#   vit_tiny_hilbert32   config 2: ViT-Tiny/16 @32, 192 / 3 heads / 12 layers / mlp 768, Hilbert, batch 256
+#   vit_tiny_raster32    config 1: the raster model of the CPU plumbing case, batch 32
+#   vit_b_hilbert224     config 3/4: ViT-B/16 @224, 768 / 12 / 12 / 3072, 1000 classes, Hilbert
+#   vit_l_{z,hilbert,raster}384  config 5: ViT-L/16 @384 widths (1024 / 16 heads / mlp 4096, N = 576, 1000 classes),
+#                        depth 2 of the 24 layers (a 24-layer fp32 CPU pass is minutes; the layers are identical code)
+FULL_CASES = {
+    "vit_tiny_hilbert32": (OracleConfig("hilbert1d", 32, 256, 3, 192, depth=12, n_heads=3, mlp_dim=768,
+                                        num_classes=10, variant="1d"), 256),
+    "vit_tiny_raster32": (OracleConfig("raster1d", 32, 256, 3, 192, depth=12, n_heads=3, mlp_dim=768,
+                                       num_classes=10, variant="1d"), 32),
+    "vit_b_hilbert224": (OracleConfig("hilbert1d", 224, 256, 3, 768, depth=12, n_heads=12, mlp_dim=3072,
+                                      num_classes=1000, variant="1d"), 2),
+    "vit_l_z384": (OracleConfig("morton1d", 384, 256, 3, 1024, depth=2, n_heads=16, mlp_dim=4096,
+                                num_classes=1000, variant="1d"), 2),
+    "vit_l_hilbert384": (OracleConfig("hilbert1d", 384, 256, 3, 1024, depth=2, n_heads=16, mlp_dim=4096,
+                                      num_classes=1000, variant="1d"), 2),
+    "vit_l_raster384": (OracleConfig("raster1d", 384, 256, 3, 1024, depth=2, n_heads=16, mlp_dim=4096,
+                                     num_classes=1000, variant="1d"), 2),
+}
+
+# name -> (model case, steps, lr, weight_decay): optimisation steps of the reference's loop body
+# (src/training/train.py:153-167 on the reference model in eval mode = dropout off; fixture train_<name>.json)
+TRAIN_CASES = {
+    "hilbert32_1d": ("hilbert32_1d", 3, 1e-3, 5e-2),
+    "raster32_2d": ("raster32_2d", 3, 1e-3, 5e-5),
+}

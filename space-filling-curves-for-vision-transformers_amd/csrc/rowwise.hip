@@ -749,33 +749,3 @@ extern "C" int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream) {
                        1.f / sqrtf(bc2));
     return check_launch("adamw");
 }
-
-
-// ---------------------------------------------------------------------------
-// Test / measurement helper: occupy `n_wgs` CUs for about `cycles` shader cycles (64 KiB of LDS per workgroup, so that
-// a 128 KiB GEMM workgroup cannot share the CU) -- stands in for an RCCL kernel that runs beside backward.
-// ---------------------------------------------------------------------------
-namespace sfcvit {
-namespace {
-__global__ __launch_bounds__(256) void occupy_kernel(long long cycles, int *sink) {
-    extern __shared__ char hog[];
-    const long long t0 = __builtin_amdgcn_s_memtime();
-    int acc = 0;
-    while (__builtin_amdgcn_s_memtime() - t0 < cycles) acc += hog[(threadIdx.x * 17 + acc) & 1023];
-    if (acc == 0x7fffffff) *sink = acc;
-}
-}  // namespace
-}  // namespace sfcvit
-
-extern "C" int sfcvit_test_occupy(int n_wgs, long long cycles, void *sink, void *stream) {
-    using namespace sfcvit;
-    if (n_wgs <= 0 || n_wgs > 256 || cycles <= 0 || cycles > (1ll << 32) || !sink) return fail(SFCVIT_EINVAL, "test_occupy: bad argument");
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess)
-            return check_launch("test_occupy attribute");
-        attr = true;
-    }
-    hipLaunchKernelGGL(occupy_kernel, dim3(n_wgs), dim3(256), 65536, static_cast<hipStream_t>(stream), cycles, static_cast<int *>(sink));
-    return check_launch("test_occupy");
-}

@@ -63,7 +63,6 @@ SIGNATURES = {
     "sfcvit_patch_embed_workspace": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sfcvit_transpose": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sfcvit_gemm_colsum_workspace": (c_int64, [c_int, c_int]),
-    "sfcvit_test_occupy": (c_int, [c_int, ctypes.c_longlong, c_void_p, c_void_p]),
     "sfcvit_last_gemm_kernel": (c_int, [ctypes.c_char_p, c_int]),
     "sfcvit_colsum_workspace": (c_int64, [c_int, c_int]),
     "sfcvit_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),

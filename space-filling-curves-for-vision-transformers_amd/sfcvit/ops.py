@@ -60,6 +60,15 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _cur_dev(t, name):
+    """One process per GPU: kernels are launched on the CURRENT device's current stream, and the library keeps
+    per-(device, stream) state (tile-queue counters).  A tensor of another device would be dereferenced through the
+    wrong context, so it is refused here rather than faulting there."""
+    if t.device.index != torch.cuda.current_device():
+        raise _lib.SfcvitError(f"{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                               "wrap the call in torch.cuda.device(tensor.device) (one process per GPU is the supported layout)")
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -68,6 +77,7 @@ def _need(t, dtype, name, dims=None):
     if not t.is_cuda:
         raise _lib.SfcvitError(f"{name}: the HIP path needs a CUDA (ROCm) tensor, got device {t.device}; "
                                "there is no CPU fallback")
+    _cur_dev(t, name)
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if dims is not None and t.dim() != dims:
@@ -81,6 +91,7 @@ def _rows2d(t, dtype, name):
     """2-D, unit inner stride, arbitrary row stride (views of packed buffers are fine)."""
     if not t.is_cuda:
         raise _lib.SfcvitError(f"{name}: the HIP path needs a CUDA (ROCm) tensor; there is no CPU fallback")
+    _cur_dev(t, name)
     if t.dtype != dtype or t.dim() != 2 or t.stride(1) != 1:
         raise ValueError(f"{name}: expected 2-D {dtype} with unit inner stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
     return t
@@ -273,12 +284,26 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0
 # ----------------------------------------------------------------------------
 # attention
 # ----------------------------------------------------------------------------
+SUPPORTED_HEAD_DIMS = (64, 128, 192, 256)
+
+
+def _attn_dims(D3, n_heads):
+    """(D, head dim) of a packed q|k|v projection; the kernels exist for head dims 64 (any N) and 128 / 192 / 256
+    (whole-sequence kernels: N <= 288 / 192 / 128)."""
+    if D3 % 3 or (D3 // 3) % n_heads:
+        raise ValueError(f"attention: packed width {D3} is not 3 * n_heads * head_dim for n_heads = {n_heads}")
+    D = D3 // 3
+    hd = D // n_heads
+    if hd not in SUPPORTED_HEAD_DIMS:
+        raise ValueError(f"attention: head dim {hd} (= {D} / {n_heads}) is not supported; supported: {SUPPORTED_HEAD_DIMS}")
+    return D, hd
+
+
 def attention_fwd(qkv, n_heads, dropout_p=0.0, dropout_seed=0):
     """qkv [B, N, 3*D] bf16 -> out [B, N, D] bf16, lse [B, H, N] fp32."""
     _need(qkv, _BF16, "attention qkv", 3)
     B, N, D3 = qkv.shape
-    D = D3 // 3
-    hd = D // n_heads
+    D, hd = _attn_dims(D3, n_heads)
     out = torch.empty((B, N, D), device=qkv.device, dtype=_BF16)
     lse = torch.empty((B, n_heads, N), device=qkv.device, dtype=torch.float32)
     a = _lib.AttnArgs()
@@ -293,8 +318,7 @@ def attention_fwd(qkv, n_heads, dropout_p=0.0, dropout_seed=0):
 def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0):
     _need(dout, _BF16, "attention dout", 3)
     B, N, D3 = qkv.shape
-    D = D3 // 3
-    hd = D // n_heads
+    D, hd = _attn_dims(D3, n_heads)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, n_heads, N), device=qkv.device, dtype=torch.float32)
     a = _lib.AttnArgs()
@@ -313,6 +337,7 @@ def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0):
 def _pe_args(x, pix, n_tokens, P, D):
     if not x.is_cuda:
         raise _lib.SfcvitError("patch_embed: the HIP path needs a CUDA (ROCm) tensor; there is no CPU fallback")
+    _cur_dev(x, "patch_embed x")
     if x.dtype not in (torch.float32, _BF16) or x.dim() != 4 or not x.is_contiguous():
         raise ValueError(f"patch_embed x: expected contiguous [B,C,H,W] fp32/bf16, got {x.dtype} {tuple(x.shape)}")
     _need(pix, torch.int32, "patch_embed pix", 2)

@@ -49,10 +49,17 @@ class _FusedTokenizer(BasePatchEmbedding):
     def _flat_table(self):          # -> 1-D integer array of length grid*grid, or None for raster
         raise NotImplementedError
 
+    def _key_buffer(self):          # the long-lived tensor the table derives from (None: raster order); subclasses whose
+        return self._flat_table()   # _flat_table() builds a temporary override this with the registered buffer
+
     def _pix_table(self, device):
-        buf = self._flat_table()
-        key = (None if buf is None else (buf.data_ptr(), buf._version), str(device))
+        # keyed on the registered buffer itself (storage, version counter, device): a hit costs three attribute reads
+        # and no kernel; load_state_dict / .to() / an in-place edit of the buffer change the key.  The flat table
+        # (a derived temporary for the [n, 2] row/col buffers) is only built on a miss.
+        reg = self._key_buffer()
+        key = (None if reg is None else (reg.data_ptr(), reg._version, str(reg.device)), str(device))
         if self._pix is None or self._pix_key != key:
+            buf = self._flat_table()
             img, p, g = self._geom
             grid = img // p
             flat = np.arange(grid * grid, dtype=np.int32) if buf is None else buf.detach().cpu().numpy()
@@ -81,6 +88,9 @@ class _Curve1D(_FusedTokenizer):
         self.embed_dim = embed_dim
         self._img_size = img_size
         self._setup(img_size, 1, patch_size, in_channels, embed_dim)
+
+    def _key_buffer(self):
+        return getattr(self, self._buffer)
 
     def _flat_table(self):
         rc = getattr(self, self._buffer)
@@ -225,6 +235,7 @@ class RandomEmbedding(_Conv2dTokenizer):
 
     def forward(self, x):
         self._perm = torch.randperm(self.n_patches)
+        self._pix_key = None                     # a new order every call: never reuse the cached pixel table
         return super().forward(x)
 
     def _flat_table(self):

@@ -30,6 +30,7 @@ class GradReducer:
         self._handles = []
         self._hooks = []
         self._param_bucket = {}
+        self._wait_events = None     # reset_stats(): (before, after) event pairs around finish()'s waits
         optimizer.grad_scale = 1.0 / self.world
 
     # -- bucket plan over the flat gradient buffer ------------------------------------------
@@ -102,10 +103,53 @@ class GradReducer:
             for b, left in enumerate(self._pending):
                 if left:
                     self._launch(b)
+        timed = self._wait_events is not None and self.world > 1 and self._handles
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self._handles:
             h.wait()
+        if timed:
+            e1.record()
+            self._wait_events.append((e0, e1))
         self._handles = []
         self._pending = None
+
+    # -- measurement (bench.py --gpus N) ------------------------------------------------------
+    def reset_stats(self):
+        """Start recording how long the compute stream is held at finish() by collectives that backward did not hide."""
+        self._wait_events = []
+
+    def stats(self, steps, reps=5):
+        """Per-step figures for the bench line: bytes reduced, the time the compute stream spent blocked on the
+        collectives (= the exposed, non-overlapped part), and -- measured afterwards with nothing else running -- the
+        time and bus bandwidth of the same bucket sequence alone (bus GB/s = 2 (w - 1) / w * bytes / time, the
+        ring-equivalent figure per GPU)."""
+        torch.cuda.synchronize()
+        exposed = sum(a.elapsed_time(b) for a, b in (self._wait_events or [])) / max(1, steps)
+        self._wait_events = None
+        out = {"buckets": len(self.buckets or []), "bucket_bytes": self.bucket_bytes,
+               "bytes_per_step": int(self.opt.flat_grad.numel() * self.opt.flat_grad.element_size()) if self.buckets else 0,
+               "exposed_ms_per_step": round(exposed, 4)}
+        if self.world > 1 and self.buckets:
+            scratch = torch.zeros_like(self.opt.flat_grad)
+            def run():
+                hs = [dist.all_reduce(scratch[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in self.buckets]
+                for h in hs:
+                    h.wait()
+            run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            out["allreduce_alone_ms"] = round(ms, 4)
+            out["bus_gbs_alone"] = round(2 * (self.world - 1) / self.world * out["bytes_per_step"] / (ms * 1e-3) / 1e9, 1)
+            out["overlapped_frac"] = round(max(0.0, 1.0 - exposed / ms), 4) if ms > 0 else None
+        return out
 
     def remove(self):
         for h in self._hooks:

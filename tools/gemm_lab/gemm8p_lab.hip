@@ -140,6 +140,21 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
         for (int r = 0; r < 16; r++) v[r] = a[r] > 0.f ? v[r] * dact_scale : 0.f;
     }
     uint16_t *c = static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n;
+#ifdef P8_LAB_NOSTORE      // lab builds only: the loop without the tile stores (results are wrong)
+    if (v[0] != 12345.678f) return;
+#endif
+#ifdef P8_LAB_STORE_SMALL  // lab builds only: the same store instructions into a 256-row window (stays in L2; results are wrong)
+    c = static_cast<uint16_t *>(g.c) + size_t(m & 255) * g.ldc + n;
+#endif
+#ifdef P8_LAB_STORE_NT     // lab builds only: non-temporal stores
+    __builtin_nontemporal_store(u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])}, reinterpret_cast<u32x4 *>(c));
+    __builtin_nontemporal_store(u32x4{pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])}, reinterpret_cast<u32x4 *>(c + 8));
+    return;
+#endif
+#ifdef P8_LAB_STORE_DIRECT // lab builds only: the fragment layout stored as it is (16 B per lane, 16 rows per quarter-wave)
+    *reinterpret_cast<u32x4 *>(c) = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    *reinterpret_cast<u32x4 *>(c + 8) = u32x4{pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+#else
     // In the fragment layout a store instruction touches 64 different 64-byte segments (16 rows per quarter-wave,
     // 16 bytes each): the vector-memory pipe takes them one by one, and the next tile's LDS-DMA queues behind them.
     // Through the patch an instruction writes 8 rows x 128 contiguous bytes.  LDS operations of one wave execute in
@@ -154,6 +169,23 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
                  : "v"(sm.wa), "v"(sm.wa ^ 16), "v"(sm.ra)
                  : "memory");
     c += sm.coff;
+#ifdef P8_LAB_NOSTORE2     // lab builds only: everything but the global store instructions (results are wrong)
+    if (g.M > 0) { asm volatile("" ::"v"(w0), "v"(w1)); return; }
+#endif
+#ifdef P8_LAB_NOSTORE_WG   // lab builds only: workgroup P8_LAB_NOSTORE_WG alone (> 0) / all but workgroup -P8_LAB_NOSTORE_WG skip the stores
+    if ((P8_LAB_NOSTORE_WG > 0) == (int(blockIdx.x) == (P8_LAB_NOSTORE_WG > 0 ? P8_LAB_NOSTORE_WG : -(P8_LAB_NOSTORE_WG)))) { asm volatile("" ::"v"(w0), "v"(w1)); return; }
+#endif
+#ifdef P8_LAB_STORE_HALF   // lab builds only: the same number of store instructions, half the bytes (results are wrong)
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_lab;
+    *reinterpret_cast<u32x2_lab *>(c) = u32x2_lab{w0[0], w0[1]};
+    *reinterpret_cast<u32x2_lab *>(c + size_t(8) * g.ldc) = u32x2_lab{w1[0], w1[1]};
+    return;
+#endif
+#ifdef P8_LAB_STORE_BITS   // lab builds only: cache-policy bits on the stores, e.g. -DP8_LAB_STORE_BITS='"sc0 sc1"'
+    asm volatile("global_store_dwordx4 %0, %1, off " P8_LAB_STORE_BITS ::"v"(c), "v"(w0) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off " P8_LAB_STORE_BITS ::"v"(c + size_t(8) * g.ldc), "v"(w1) : "memory");
+    return;
+#endif
     // Streaming stores (system scope + non-temporal): C is far larger than the L2 and is next read by another kernel;
     // written through, it does not push the B panel and the A rows the other workgroups are loading out of the L2
     // (measured with the cache-policy bits one by one, same process: plain 181 / 246 / 227 us for QKV / FFN1 / FFN2
@@ -162,8 +194,26 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
     // only for stores it emitted itself.
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(c), "v"(w0) : "memory");
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(c + size_t(8) * g.ldc), "v"(w1) : "memory");
+#endif
 }
 
+#ifdef P8_LAB_TRACE         // lab builds only: shader-clock stamps of workgroup P8_LAB_TRACE, waves 0 and 4, through LDS
+__device__ unsigned long long p8_trace[2][256];
+#define P8_STAMP()                                                                                                   \
+    do {                                                                                                             \
+        if ((tid & 255) == 0 && blockIdx.x == P8_LAB_TRACE && tr_n < 256)                                           \
+            reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 8192)[(tid >> 8) * 256 + tr_n] = __builtin_amdgcn_s_memtime(); \
+        tr_n++;                                                                                                      \
+    } while (0)
+#ifdef P8_LAB_TRACE_PHASE   // also one stamp after the first barrier of phases 0-2
+#define P8_STAMP_PHASE() P8_STAMP()
+#else
+#define P8_STAMP_PHASE()
+#endif
+#else
+#define P8_STAMP()
+#define P8_STAMP_PHASE()
+#endif
 
 template <int NI, int MASK>
 __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, unsigned *__restrict__ counters) {
@@ -174,6 +224,9 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 2, wc = wid & 3;
     const int q = lane >> 4, nl = lane & 15;
     const int K = g.K, NT = g.N / 256, ntiles = (g.M / BM) * NT, KT = K / 64;
+#ifdef P8_LAB_TRACE
+    int tr_n = 0;
+#endif
     const uint16_t *A = static_cast<const uint16_t *>(g.a);
     const uint16_t *B = static_cast<const uint16_t *>(g.b);
     // Tile queue.  XCD x (blockIdx % 8: where the dispatcher puts this workgroup, a locality heuristic only) owns the
@@ -198,6 +251,13 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
             }
         }
     };
+#ifdef P8_LAB_STAGGER      // lab builds only (tools/gemm_lab/README.md): start the workgroups of an XCD in P8_LAB_SLOTS time slots
+                           // spread over P8_LAB_STAGGER ns per k-tile
+    {
+        const uint64_t until = wall_clock64() + uint64_t((blockIdx.x >> 3) % P8_LAB_SLOTS) * uint64_t(KT) * P8_LAB_STAGGER / (10 * P8_LAB_SLOTS);
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     if (tid == 0) {
         // two separate draws: every workgroup of the XCD first takes one tile of the first chunk of 32, then one of the
         // second.  (One draw of two would hand a workgroup two column tiles of the same A panel to compute one after
@@ -251,7 +311,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     };
     // Where the cursors go when they leave the current tile: the operand origins of the workgroup's next tile, worked
     // out (queue entry from LDS, two 64-bit multiplies) during the first k-tile of every tile, behind that phase's
-    // MFMAs -- done at the crossing itself it cost every wave ~800 clocks per tile (measured with the stamped lab build, tools/gemm_lab/gemm8p_lab.hip).
+    // MFMAs -- done at the crossing itself it cost every wave ~800 clocks per tile (measured with P8_LAB_TRACE).
     const uint16_t *next_a = nullptr, *next_b = nullptr;
     auto set_next = [&](int seq) __attribute__((always_inline)) {
         const Cursor na = cursor_at(seq, __builtin_amdgcn_readfirstlane(tq[seq & 3]), true);
@@ -359,6 +419,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         }
     };
     auto epilogue = [&]() __attribute__((always_inline)) {
+        P8_STAMP();
         const int tile = tile_cur;
         // Everything lane-dependent is rebuilt here from the thread index behind an empty asm: left to itself the
         // compiler hoists it out of the k-loop, where there is no register to keep it in.
@@ -432,7 +493,11 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
                     *reinterpret_cast<f32x4 *>(pp + 4 * r4) = f32x4{cs[4 * r4], cs[4 * r4 + 1], cs[4 * r4 + 2], cs[4 * r4 + 3]};
             }
         }
+#ifdef P8_LAB_ACKWAIT      // lab builds only: wait for the stores' acknowledgements before the next tile
+        wait_vm<0>();
+#endif
         zero_acc();
+        P8_STAMP();
     };
 
     // --- prologue: the state the loop expects at phase 0 of k-tile 0 ---
@@ -473,12 +538,14 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         read_b(fb0, buf, 0);
         read_a0(buf);
         bar();
+        P8_STAMP_PHASE();
         wait_lgkm<0>();
         mma0(fb0, 0);
         bar();
         // phase 1: a1 x b0
         read_a1(buf);
         bar();
+        P8_STAMP_PHASE();
         wait_lgkm<0>();
         mma1(fb0, 0);
         if (first) set_next(t + 1);           // entry t + 1 was published an epilogue and several barriers ago
@@ -487,6 +554,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         read_b(fb1, buf, 1);
         stage_b(cb, buf, 0);
         bar();
+        P8_STAMP_PHASE();
         wait_lgkm<0>();
         mma1(fb1, 1);
         bar();
@@ -495,10 +563,11 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         if (first && t > 0) wait_vm<4 + NSTORE>();   // the whole next k-tile has landed; the stores may still be out
         else wait_vm<4>();
         bar();
+        P8_STAMP();
         mma0(fb1, 1);
         // ONE copy of the epilogue code (group 1 runs it before, group 0 after the tile's last barrier), so that the
         // other k-tiles branch over it once, not twice: a taken branch across ~5 KB of code costs ~100 clocks
-        // (measured with the stamped lab build: the k-tile pairs that contained the two jumps were 300 clocks longer)
+        // (measured with P8_LAB_TRACE: the k-tile pairs that contained the two jumps were 300 clocks longer)
         if (last) {
             if (wr == 0) {
                 bar();
@@ -527,6 +596,11 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     }
     if (wr == 0) bar();
     wait_vm<0>();
+#ifdef P8_LAB_TRACE
+    if ((tid & 255) == 0 && blockIdx.x == P8_LAB_TRACE)
+        for (int i = 0; i < 256; i++)
+            p8_trace[tid >> 8][i] = i < tr_n ? reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 8192)[(tid >> 8) * 256 + i] : 0ull;
+#endif
     finish();
 }
 
@@ -706,62 +780,39 @@ __global__ __launch_bounds__(T) void gemm8p_km_kernel(const sfcvit_gemm_args g, 
             *reinterpret_cast<f32x4 *>(slab + size_t((i >> 2) * 128 + (i & 3) * 16) * g.N + (j >> 1) * 128 + (j & 1) * 16) = acc[i][j];
 }
 
-// Nine zero-initialised counters per (device, stream) (tile queues of the 8 XCDs + finished workgroups); every launch
-// leaves them zero again, and launches on one stream are ordered, so a (device, stream) pair can keep its slot for
-// ever.  Rule (include/sfcvit.h): one launch at a time per slot, i.e. a captured graph holding these kernels must not
-// be replayed on two streams at once.  Each device has its own pool, allocated at the first call on that device
-// (which must therefore not sit inside a hipGraph capture: warm up first); handing a slot to a new stream -- a
-// capture stream, say -- allocates nothing.  A launch that fails re-zeroes its slot (requeue_reset).
-struct DeviceState {
-    unsigned *pool = nullptr;
-    int next = 0;
-    int cus = 0;
-    std::unordered_map<hipStream_t, unsigned *> per_stream;
-};
-constexpr int MAX_DEVICES = 64, SLOTS = 1024, SLOT_UINTS = 16;
-std::mutex g_mu;
-DeviceState g_dev[MAX_DEVICES];
-
-DeviceState *device_state() {              // the CURRENT device's state (g_mu held by the caller)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
-    DeviceState *d = &g_dev[dev];
-    if (!d->cus) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
-        d->cus = prop.multiProcessorCount;
-    }
-    return d;
-}
-
-int device_cus() {
-    std::lock_guard<std::mutex> lock(g_mu);
-    DeviceState *d = device_state();
-    return d ? d->cus : 0;
-}
-
+// Nine zero-initialised counters per stream (tile queues of the 8 XCDs + finished workgroups); every launch leaves
+// them zero again, and launches on one stream are ordered, so a stream can keep its slot for ever.  The slots come
+// from one pool allocated at the first call (which must therefore not sit inside a hipGraph capture: warm up first);
+// handing a slot to a new stream -- a capture stream, say -- allocates nothing.
 unsigned *queue_counters(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(g_mu);
-    DeviceState *d = device_state();
-    if (!d) return nullptr;
-    auto it = d->per_stream.find(s);
-    if (it != d->per_stream.end()) return it->second;
-    if (!d->pool) {
-        if (hipMalloc(reinterpret_cast<void **>(&d->pool), size_t(SLOTS) * SLOT_UINTS * sizeof(unsigned)) != hipSuccess ||
-            hipMemset(d->pool, 0, size_t(SLOTS) * SLOT_UINTS * sizeof(unsigned)) != hipSuccess) {
-            d->pool = nullptr;
+    constexpr int SLOTS = 1024, SLOT_UINTS = 16;
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, unsigned *> per_stream;
+    static unsigned *pool = nullptr;
+    static int next = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_stream.find(s);
+    if (it != per_stream.end()) return it->second;
+    if (!pool) {
+        if (hipMalloc(reinterpret_cast<void **>(&pool), size_t(SLOTS) * SLOT_UINTS * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(pool, 0, size_t(SLOTS) * SLOT_UINTS * sizeof(unsigned)) != hipSuccess) {
+            pool = nullptr;
             return nullptr;
         }
     }
-    if (d->next >= SLOTS) return nullptr;        // 1024 distinct streams on one device: not a case worth more code
-    unsigned *p = d->pool + size_t(d->next++) * SLOT_UINTS;
-    d->per_stream[s] = p;
+    if (next >= SLOTS) return nullptr;           // 1024 distinct streams in one process: not a case worth more code
+    unsigned *p = pool + size_t(next++) * SLOT_UINTS;
+    per_stream[s] = p;
     return p;
 }
 
 template <int NI, int MASK>
 int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
+#ifdef P8_LAB_TRACE
+    const int LDS_TOTAL = LDS_MAX;
+#else
     const int LDS_TOTAL = LDS_BIAS + (a.bias ? a.N * 2 : 0);
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>),
@@ -773,9 +824,7 @@ int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
     if (!counters) return fail(SFCVIT_ELAUNCH, "gemm8p: could not allocate the tile-queue counters");
     note_gemm_kernel(1, NI, MASK);
     hipLaunchKernelGGL((gemm8p_kernel<NI, MASK>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters);
-    const int rc = check_launch("gemm8p");
-    if (rc) (void)hipMemsetAsync(counters, 0, SLOT_UINTS * sizeof(unsigned), s);   // a launch that did not run leaves no debt
-    return rc;
+    return check_launch("gemm8p");
 }
 
 template <int NI>
@@ -801,8 +850,13 @@ int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_us
     using namespace p8;
     if (!a.a_kmajor || !a.b_kmajor || splits_req < 2) return -1;
     if (a.M % 256 || a.N % 256 || a.K % 128 || a.lda % 8 || a.ldb % 8) return -1;
-    const int cus = device_cus();
-    if (!cus) return -1;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        cus = prop.multiProcessorCount;
+    }
     const int tiles = (a.M / 256) * (a.N / 256), KT = a.K / 64;
     int splits = cus / tiles;                                     // one workgroup per CU
     if (splits > splits_req) splits = splits_req;
@@ -844,8 +898,14 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     if (a.colsum_out) mask |= CSUM;                          // built with DACT only; other combinations fall back
     if ((mask & DACT) && a.bias) return -1;                  // the DACT variants leave the bias out (register room)
     if (a.bias && a.N > BIAS_MAX_N) return -1;               // the bias vector lives in LDS
-    const int cus = device_cus() / 8 * 8;
-    if (cus < 8) return -1;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        cus = prop.multiProcessorCount / 8 * 8;
+        if (cus < 8) return -1;
+    }
     // Tile height: the one whose last round of tiles wastes least (cost = rounds x rows per tile).
     const int nt = a.N / 256;
     long best = -1;
@@ -872,3 +932,8 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
 
 }  // namespace sfcvit
 
+#ifdef P8_LAB_TRACE
+extern "C" int sfcvit_lab_trace(unsigned long long *host) {
+    return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(sfcvit::p8::p8_trace), sizeof(unsigned long long) * 512));
+}
+#endif

@@ -4,7 +4,9 @@
 launch for every sfcvit kernel.  rocprofv3 reports both counters in KiB; FETCH_SIZE is doubled (on gfx950 it tallies
 the 128-B requests of 16-B/lane streaming reads as 64 B, MI355X_MICROARCH.md "HBM"), WRITE_SIZE is taken as is.
 
-    python tools/traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <build tag>
+    python tools/traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <build tag> [workload]
+
+The file is keyed by bench.py workload (default vit_b16_224_hilbert); other workloads' entries are kept.
 """
 import csv
 import json
@@ -34,6 +36,14 @@ def per_kernel(path, counter):
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    workload = sys.argv[4] if len(sys.argv) > 4 else "vit_b16_224_hilbert"
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        doc = {}
+    doc.setdefault("workloads", {})
     out = {"_comment": "HBM-side traffic per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE "
                        "passes over `bench.py --steps 3 --warmup 1`), averaged over all launches of the kernel. bytes = counter "
                        "value x 1024; FETCH_SIZE is then doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streaming "
@@ -47,8 +57,10 @@ def main():
         w, _ = write.get(k, (0.0, 0))
         out["kernels"][k] = {"fetch_bytes_raw": f * 1024, "fetch_bytes_corrected": 2 * f * 1024, "write_bytes": w * 1024,
                              "traffic_bytes": 2 * f * 1024 + w * 1024, "launches_sampled": nf}
-    with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as fo:
-        json.dump(out, fo, indent=1)
+    doc["_comment"] = out.pop("_comment") + " Keyed by bench.py workload."
+    doc["workloads"][workload] = out
+    with open(path, "w") as fo:
+        json.dump(doc, fo, indent=1)
     for k, v in out["kernels"].items():
         print(f"{k:60s} {v['traffic_bytes'] / 1e6:10.1f} MB/launch ({v['launches_sampled']} launches)")
 
