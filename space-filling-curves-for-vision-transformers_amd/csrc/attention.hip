@@ -17,6 +17,7 @@
 //       dV^T += dO^T P, dK^T += Q^T dS   A: tr-reads of dO / Q   B: P / dS accumulators
 //   backward, dQ kernel    (wave = 16 queries, loop over 64-key blocks in LDS)
 //       S^T = K Q^T, dP^T = V dO^T ; dQ^T += K^T dS^T  (A: tr-read of K, B: dS^T)
+#include <cstdlib>
 #include "attention_common.h"
 #include "common_host.h"
 
@@ -316,6 +317,8 @@ int check_args(const sfcvit_attn_args *a, const char *what, bool bwd) {
 // attention_seq.hip: whole-sequence kernels; return -1 when N is too long for them.
 int attn_seq_fwd(const sfcvit_attn_args &a, hipStream_t s);
 int attn_seq_bwd(const sfcvit_attn_args &a, hipStream_t s);
+// attention_bwd_fused.hip: dK, dV and dQ in one pass (head dim 64, N <= 224); -1 when not eligible.
+int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s);
 // attention_wide.hip: head dims 128 / 192 / 256; return -1 for head dim 64.
 int attn_wide_fwd(const sfcvit_attn_args &a, hipStream_t s);
 int attn_wide_bwd(const sfcvit_attn_args &a, hipStream_t s);
@@ -341,6 +344,9 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
                        static_cast<const uint16_t *>(a->dout), static_cast<const uint16_t *>(a->out), a->delta, a->B, a->N, a->H, a->hd);
     if (int rc = check_launch("attention_bwd delta")) return rc;
     if (int rc = attn_wide_bwd(*a, s); rc >= 0) return rc;
+    const char *env = getenv("SFCVIT_ATTN_BWD_FUSED");       // "0": the two-kernel form (A/B measurements, tests)
+    if (!(env && env[0] == '0'))
+        if (int rc = attn_seq_bwd_fused(*a, s); rc >= 0) return rc;
     if (int rc = attn_seq_bwd(*a, s); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
     hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(THREADS), 0, s, *a);

@@ -1,0 +1,243 @@
+// Fused attention backward for gfx950 (head dim 64, N <= 224: ViT-B/16 @ 224 has N = 196): dK, dV AND dQ of one
+// (batch, head) in ONE pass over the scores -- five MFMA products per score tile (S, dP, dV, dK, dQ) instead of the
+// seven of the two-kernel form (attention_seq.hip: a dK/dV kernel and a dQ kernel that each recompute S and dP), the
+// exp / dropout-hash / dS arithmetic once instead of twice, and q, k, v, dO read from HBM once instead of twice.
+//
+//   * one workgroup of 16 waves per (batch, head); Q, dO and K of the whole sequence are staged once into LDS by
+//     LDS-DMA (3 x 28 KiB at N = 196); every KEY wave (wave w < nf owns the 16 keys 16w .. 16w+15) fetches its K / V
+//     fragments straight into registers, so V never touches LDS.
+//   * the sequence is walked in chunks of 32 queries.  In chunk c a key wave computes S^T and dP^T of its keys against
+//     the chunk's queries (key on the MFMA lane: the accumulators are the B operands of the dV and dK products without
+//     any data movement), turns them into P and dS, adds P^T dO into dV and dS^T Q into dK -- exactly the loop body of
+//     attn_seq_bwd_kv_kernel -- and additionally writes its [16 keys][32 queries] block of dS^T (bf16) into a
+//     double-buffered exchange image in LDS.
+//   * the last two waves are dQ waves: in chunk c they read the complete dS^T image of chunk c - 1 ([keys][32 queries],
+//     transposed reads) and K^T (transposed reads of the K image) and produce dQ^T = K^T dS^T for those 32 queries,
+//     32 head columns each, and store it.  One workgroup barrier per chunk orders writer and reader; the two halves of
+//     the exchange image alternate.  Every dQ tile is summed by one wave in a fixed key order: results are bit-identical
+//     from run to run (no atomics).
+//   * rows >= N: the DMA fills them with copies of row N - 1 (finite); padded queries get lse = +inf (P = dS = 0), padded
+//     keys get dS = 0 before the exchange and their dK / dV rows are not stored; exchange rows of keys >= 16 nf are
+//     zeroed once.
+#include "attention_common.h"
+#include "common_host.h"
+
+namespace sfcvit {
+namespace {
+
+using namespace attn;
+
+constexpr int FT = 1024, FWAVES = 16, FMAXC = 7;   // threads, waves, 32-row chunks (N <= 224)
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// Stage npad rows x 64 cols (128-B rows) into a kc image by LDS-DMA; the bank swizzle goes on the SOURCE chunk
+// (the DMA writes lane-linear); rows >= N copy row N - 1.
+__device__ __forceinline__ void dma_rows(char *img, const uint16_t *__restrict__ src, int ld, int N, int npad, int tid) {
+    for (int p = tid; p < npad * 8; p += FT) {
+        const int row = p >> 3, cs = p & 7;
+        const int c = cs ^ ((row >> 1) & 7);
+        const uint16_t *g = src + size_t(min(row, N - 1)) * ld + c * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(img + p * 16), 16, 0, 0);
+    }
+}
+
+// dS^T exchange image: [key rows][32 queries] bf16, 64-B rows; the two 32-B halves (query fragment 0 / 1 of the chunk)
+// are swapped on rows with (row >> 2) & 1 set, which makes both the 8-byte writes of a key wave and the transposed
+// reads of a dQ wave spread over all banks.
+__device__ __forceinline__ bf16x8 ds_tr_frag(const char *slot, int key0, int lane_off) {
+    const char *pa = slot + key0 * 64 + lane_off;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFCVIT_LDS bf16x4 *)pa);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFCVIT_LDS bf16x4 *)(pa + 16 * 64));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// NFC: number of 16-row fragments at compile time (0 = from N); DROP: dropout on the probabilities (compile-time: a
+// runtime flag put a branch around every hash, each one a scheduling barrier between the MFMAs).
+template <int NFC, bool DROP>
+__global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_attn_args a, int npad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *qimg = smem, *doimg = smem + npad * 128, *kimg = smem + 2 * npad * 128, *dsb = smem + 3 * npad * 128;
+    float *lse_s = reinterpret_cast<float *>(dsb + 2 * npad * 64), *del_s = lse_s + npad;
+    uint32_t *rkey_s = reinterpret_cast<uint32_t *>(del_s + npad);   // dropout row key of every query
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, h = blockIdx.x, N = a.N, D = a.H * HD, ld = 3 * D;
+    const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
+    const uint16_t *qp = base, *kp = base + D, *vp = base + 2 * D;
+    const uint16_t *dop = static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD;
+    const float *lse = a.lse + (size_t(b) * a.H + h) * N, *del = a.delta + (size_t(b) * a.H + h) * N;
+    const int nf = NFC ? NFC : (N + 15) >> 4, nc = NFC ? ((NFC + 1) >> 1) : npad >> 5;
+    const bool is_key = wave < nf, is_dq = wave >= FWAVES - 2;
+    bf16x8 kf[2], vf[2];                              // this wave's 16 keys: V from HBM here, K from the staged image below
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) vf[kk] = global_frag(vp, ld, 16 * wave, is_key ? N : 0, kk, lane);
+    dma_rows(qimg, qp, ld, N, npad, tid);
+    dma_rows(doimg, dop, D, N, npad, tid);
+    dma_rows(kimg, kp, ld, N, npad, tid);
+    const uint32_t dth = drop_thresh(a.dropout_p);
+    for (int i = tid; i < npad; i += FT) {
+        lse_s[i] = i < N ? lse[i] * 1.4426950408889634f : INFINITY;   // padded queries: p = exp2(-inf) = 0
+        del_s[i] = i < N ? del[i] : 0.f;
+        rkey_s[i] = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(i));
+    }
+    {   // exchange rows no key wave writes (keys 16 nf .. npad - 1), both halves of the double buffer
+        const int nz = (npad - 16 * nf) * 4;         // 16-byte pieces per half
+        for (int i = tid; i < 2 * nz; i += FT) {
+            char *dst = dsb + (i >= nz ? npad * 64 : 0) + 16 * nf * 64 + (i >= nz ? i - nz : i) * 16;
+            *reinterpret_cast<u32x4 *>(dst) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __syncthreads();                                  // LDS-DMA pending: hipcc drains vmcnt(0) here
+
+    const float scale = a.scale, c2 = a.scale * 1.4426950408889634f;
+    const LaneOff lo = lane_offsets(lane);
+    const float dsc = 1.f / (1.f - a.dropout_p);
+    uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
+    const int g = lane >> 4, li = lane & 15;
+    const int key = 16 * wave + li;                   // key waves: the key this lane's accumulator columns belong to
+    if (is_key) {                                     // rows >= N of the image copy row N - 1: those keys are masked below
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) kf[kk] = kc_frag_at(kimg, 16 * wave, lo.k[kk]);
+    } else {
+        kf[0] = kf[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int hf = 0; hf < 4; hf++) dk[hf] = dv[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c <= nc; c++) {
+        if (is_key && c < nc) {
+            char *slot = dsb + (c & 1) * npad * 64;
+            f32x4 p[2], ds[2];
+            // exchange image, writer side: row key, query fragment t at half t ^ ((key >> 2) & 1), 8 bytes at 8 g
+            const int ds_w = key * 64 + (((li >> 2) & 1) << 5) + 8 * g;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int qf = 2 * c + t;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(qimg, 16 * qf, lo.k[kk]), kf[kk], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(doimg, 16 * qf, lo.k[kk]), vf[kk], dp, 0, 0, 0);
+                }
+                const int ql0 = 16 * qf + 4 * g;                     // this lane's 4 queries: one 16-B LDS read each
+                const f32x4 lse4 = *reinterpret_cast<const f32x4 *>(lse_s + ql0);    // lse * log2(e)
+                const f32x4 del4 = *reinterpret_cast<const f32x4 *>(del_s + ql0);
+                const u32x4 rk4 = *reinterpret_cast<const u32x4 *>(rkey_s + ql0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float pv = fast_exp2(s[r] * c2 - lse4[r]);
+                    float keep = 1.f;                                 // 1 / (1 - p) where the element is kept, else 0
+                    if (DROP) {
+                        bool k0b, k1b;
+                        drop_keep2(rk4[r], uint32_t(key >> 1), dth, k0b, k1b);
+                        keep = ((key & 1) ? k1b : k0b) ? dsc : 0.f;
+                    }
+                    p[t][r] = pv * keep;
+                    ds[t][r] = pv * (dp[r] * keep - del4[r]);             // x scale at the stores of dK and dQ
+                }
+                if (16 * wave + 16 > N) {                            // boundary fragment (wave-uniform): keys >= N carry no gradient
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (key >= N) ds[t][r] = 0.f;
+                }
+            }
+            const bf16x8 pf = pack_frag(p[0], p[1]), dsf = pack_frag(ds[0], ds[1]);
+            {   // dS^T for the dQ waves: 4 consecutive queries of fragment t = 8 bytes
+                const u32x4 w = __builtin_bit_cast(u32x4, dsf);
+                *reinterpret_cast<u32x2 *>(slot + ds_w) = u32x2{w[0], w[1]};
+                *reinterpret_cast<u32x2 *>(slot + (ds_w ^ 32)) = u32x2{w[2], w[3]};
+            }
+#pragma unroll
+            for (int hf = 0; hf < 4; hf++) {
+                dv[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_at(doimg, 32 * c, lo.t[hf]), pf, dv[hf], 0, 0, 0);
+                dk[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_at(qimg, 32 * c, lo.t[hf]), dsf, dk[hf], 0, 0, 0);
+            }
+        } else if (is_dq && c >= 1) {
+            const char *slot = dsb + ((c - 1) & 1) * npad * 64;
+            // (lane constants of the dQ role are worked out here, per chunk, rather than kept live across the key waves' loop:
+            // every wave runs the same kernel and the register file is full)
+            // reader side: rows 4 g + (li >> 2) (+ 16), query columns 16 qf + 4 (li & 3): half qf ^ (g & 1)
+            const int ds_r = (4 * g + (li >> 2)) * 64 + ((g & 1) << 5) + 8 * (li & 3);
+            const int dqw = wave - (FWAVES - 2);              // head columns 32 dqw .. 32 dqw + 31
+            int kt_off[2];                                    // K^T fragments of those columns (kc image, transposed read)
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int col = 16 * (2 * dqw + hh) + 4 * (li & 3), tr = 4 * g + (li >> 2);
+                kt_off[hh] = kc_off(tr, col >> 3) + ((col & 7) << 1);
+            }
+            f32x4 acc[2][2];                                         // [head-column fragment hh][query fragment qf]
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < FMAXC; ks++) {
+                if (ks < nc) {                                       // key steps of 32 (keys are padded like the queries)
+                    const bf16x8 b0 = ds_tr_frag(slot, 32 * ks, ds_r), b1 = ds_tr_frag(slot, 32 * ks, ds_r ^ 32);
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        const bf16x8 kt = tr_frag_at(kimg, 32 * ks, kt_off[hh]);
+                        acc[hh][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, b0, acc[hh][0], 0, 0, 0);
+                        acc[hh][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, b1, acc[hh][1], 0, 0, 0);
+                    }
+                }
+            }
+            mfma_fence();
+            // acc[hh][qf][r] = dQ[query 32 (c-1) + 16 qf + li][head column 32 dqw + 16 hh + 4 g + r]
+#pragma unroll
+            for (int qf = 0; qf < 2; qf++) {
+                const int q = 32 * (c - 1) + 16 * qf + li;
+                if (q < N) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        const u32x2 o = {pack2bf(acc[hh][qf][0] * scale, acc[hh][qf][1] * scale),
+                                         pack2bf(acc[hh][qf][2] * scale, acc[hh][qf][3] * scale)};
+                        *reinterpret_cast<u32x2 *>(dbase + size_t(q) * ld + 32 * dqw + 16 * hh + 4 * g) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (is_key) {
+        mfma_fence();
+        store_rows(dbase + D, ld, key, key < N, dk, scale, lane);
+        store_rows(dbase + 2 * D, ld, key, key < N, dv, 1.f, lane);
+    }
+}
+
+constexpr int FUSED_MAX_N = 32 * FMAXC;
+constexpr int FUSED_ROW_BYTES = 3 * 128 + 2 * 64 + 3 * 4;    // LDS bytes per padded sequence row
+constexpr int FUSED_MAX_LDS = FUSED_MAX_N * FUSED_ROW_BYTES;
+
+}  // namespace
+
+// -1: not eligible (the caller falls back to the two-kernel form); else a status.
+int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s) {
+    if (a.hd != HD || a.N > FUSED_MAX_N) return -1;
+    static bool done = false;
+    if (!done) {
+        for (const void *k : {reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<0, false>),
+                              reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<0, true>),
+                              reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<13, false>),
+                              reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<13, true>)})
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS) != hipSuccess)
+                return check_launch("attention_bwd_fused attribute");
+        done = true;
+    }
+    const int npad = (a.N + 31) / 32 * 32;
+    const size_t lds = size_t(npad) * FUSED_ROW_BYTES;
+    const bool nf13 = (a.N + 15) / 16 == 13, drop = a.dropout_p > 0.f;
+    const dim3 grid(a.H, a.B), block(FT);
+    if (nf13 && drop) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<13, true>), grid, block, lds, s, a, npad);
+    else if (nf13) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<13, false>), grid, block, lds, s, a, npad);
+    else if (drop) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<0, true>), grid, block, lds, s, a, npad);
+    else hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<0, false>), grid, block, lds, s, a, npad);
+    return check_launch("attention_bwd_fused");
+}
+
+}  // namespace sfcvit
+

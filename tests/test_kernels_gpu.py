@@ -494,3 +494,31 @@ def test_ops_are_hipgraph_capturable(ops):
     assert torch.equal(y, ops.gemm(a2, w, bias=bias))
     assert torch.equal(z, ops.layernorm_fwd(y, gam, bet, 1e-5)[0])
     assert torch.equal(o, ops.attention_fwd(q2, 2)[0])
+
+
+@pytest.mark.parametrize("B,N,H,p", [(3, 196, 2, 0.0), (2, 196, 3, 0.1), (2, 224, 1, 0.1), (2, 33, 2, 0.0), (1, 200, 2, 0.1),
+                                     (2, 4, 1, 0.1), (1, 209, 1, 0.0)])
+def test_attention_bwd_fused_vs_two_kernel_form(ops, B, N, H, p, monkeypatch):
+    """The single-pass backward (attention_bwd_fused.hip: dK, dV and dQ from one evaluation of P and dS, dS handed to
+    the dQ waves through LDS) against the two-kernel form (SFCVIT_ATTN_BWD_FUSED=0) and against fp32 math; run twice
+    for bit-reproducibility (every dQ tile is summed by one wave in a fixed order)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    D, seed = H * 64, 777
+    qkv = bf(torch.randn(B, N, 3 * D, device="cuda", generator=g))
+    dout = bf(torch.randn(B, N, D, device="cuda", generator=g))
+    out, lse = ops.attention_fwd(qkv, H, p, seed)
+    monkeypatch.setenv("SFCVIT_ATTN_BWD_FUSED", "0")
+    two = ops.attention_bwd(qkv, out, lse, dout, H, p, seed)
+    monkeypatch.setenv("SFCVIT_ATTN_BWD_FUSED", "1")
+    one = ops.attention_bwd(qkv, out, lse, dout, H, p, seed)
+    again = ops.attention_bwd(qkv, out, lse, dout, H, p, seed)
+    assert torch.equal(one, again)
+    close(one, two.float(), rel=1 / 128, abs_scale=1 / 64)
+    mask = ops.dropout_mask(B * H * N, N, p, seed).float().view(B, H, N, N) if p > 0 else 1.0
+    qf = qkv.float().requires_grad_(True)
+    q, k, v = qf.split(D, dim=-1)
+    sp = lambda t: t.reshape(B, N, H, 64).transpose(1, 2)
+    s = (sp(q) @ sp(k).transpose(-1, -2)) / 8.0
+    ref = ((torch.softmax(s, -1) * mask) @ sp(v)).transpose(1, 2).reshape(B, N, D)
+    ref.backward(dout.float())
+    close(one, qf.grad, rel=1 / 48, abs_scale=1 / 24)
