@@ -92,7 +92,20 @@ typedef struct sfcvit_patch_embed_args {
     int32_t B, C, HW, N, P, D; /* N*P = H*W; D a multiple of 8; P*C arbitrary (padded to 8 inside; the
                                   vectorised table reads need P % 8 == 0, other P take a scalar gather) */
     int32_t x_is_bf16;
+    /* Optional tile descriptor (device copy of what sfcvit_tile_descriptors wrote; NULL = generic kernels).  With it,
+     * P = 256 and D % 256 == 0 the forward runs the tiled kernel (csrc/patch_embed_tiled.hip: whole 16-pixel row
+     * segments loaded with 16-byte vectors straight into the LDS tile, the intra-tile curve order folded into a
+     * per-class permuted weight).  desc_ncls / desc_cnt = its classes and tokens per class (host copies);
+     * the forward workspace must then hold desc_ncls * D * C * 256 bf16. */
+    const int32_t *desc;
+    int32_t desc_ncls;
+    int32_t desc_cnt[8];
 } sfcvit_patch_embed_args;
+
+/* HOST: analyse a pixel table (host copy of sfcvit_pixel_table's output): > 0 = number of int32 written to `desc`
+ * (every token is a 16 x 16 pixel tile or a strip of 256 consecutive pixels), 0 = not tileable, < 0 = error.
+ * Capacity 16 + 2 N + 8 * 256 always suffices. */
+int sfcvit_tile_descriptors(const int32_t *pix, int N, int P, int img_w, int32_t *desc, int capacity);
 
 /* HOST: workspace bytes for fwd (bwd = 0) / bwd (bwd = 1). */
 int64_t sfcvit_patch_embed_workspace(int B, int C, int N, int P, int D, int bwd);

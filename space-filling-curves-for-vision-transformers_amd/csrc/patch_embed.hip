@@ -231,12 +231,16 @@ Geo make_geo(const sfcvit_patch_embed_args *a) {
 }  // namespace
 }  // namespace sfcvit
 
+namespace sfcvit {
+int pe2_fwd(const sfcvit_patch_embed_args &a, hipStream_t s);      // patch_embed_tiled.hip; -1 = not eligible
+}
+
 using namespace sfcvit;
 
 extern "C" int64_t sfcvit_patch_embed_workspace(int B, int C, int N, int P, int D, int bwd) {
     if (B <= 0 || C <= 0 || N <= 0 || P <= 0 || D <= 0) return 0;
     const int64_t K = (int64_t(C) * P + 7) / 8 * 8;
-    if (!bwd) return ((int64_t(D) * K * 2 + 15) / 16) * 16;
+    if (!bwd) return ((int64_t(D) * K * 2 * 8 + 15) / 16) * 16;      // up to 8 class-permuted copies of W (tiled forward)
     const int64_t slabs = int64_t(bwd_splits(B * N, D, int(K))) * D * K * int64_t(sizeof(float));
     const int64_t bias_ws = sfcvit_colsum_workspace(B * N, D);   // dbias reuses the buffer after the slabs are reduced
     return slabs > bias_ws ? slabs : bias_ws;
@@ -249,6 +253,7 @@ extern "C" int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *st
     if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace))
         return fail(SFCVIT_EINVAL, "patch_embed_fwd: workspace of %lld bytes needed", (long long)need);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = pe2_fwd(*a, s); rc >= 0) return rc;                 // tiles / strips: the coalesced kernel
     const Geo g = make_geo(a);
     uint16_t *wp = static_cast<uint16_t *>(a->workspace);
     const int64_t nw = int64_t(a->D) * g.Kp;

@@ -1,0 +1,300 @@
+// Fused SFC gather + patchify + projection, TILED form (gfx950) -- the BASELINE tokenizers.
+//
+// At every BASELINE size (32, 224, 384 px; 256 curve pixels per token) each token of the Hilbert / Z order is ONE
+// 16 x 16 pixel tile of the image, visited in the curve's order, with one of <= 4 pixel orders
+// inside the tile ("classes"; 1 for Z); a raster token (zigzag_embedding1D.py:30-39) is a strip of 256 consecutive
+// pixels.  So a token's 768 features are 48 contiguous row segments of 16 pixels, and the curve is two small tables:
+// the tile origin per token and the intra-tile permutation per class.  The permutation is folded into the WEIGHT
+// (W'[class][d][c*256 + r*16 + x] = W[d][curve_pos_class(r, x)*C + c], one tiny kernel per call), after which
+//     tokens(b, n) . W^T  ==  image_tile(b, n) (raster order inside the tile) . W'[class(n)]^T            exactly,
+// i.e. the same products summed in a different order.  The gather is then the A-operand loader of an MFMA GEMM:
+//
+//   * forward: one workgroup = 128 token rows (all of one class; rows = (token, image) pairs) x 256 output columns;
+//     per k-tile (64 features = 4 tile rows of one channel) every thread loads ONE 16-pixel row segment (64 B fp32 /
+//     32 B bf16, 16-byte vector loads: whole segments, fully used cache lines), converts it to bf16 and writes it into
+//     the swizzled LDS tile; W' streams through an LDS-DMA double buffer; 16x16x32 bf16 MFMA, fp32 accumulate; the
+//     bias is added and the rows are stored straight to out[b, n, :].  The three column tiles of a row tile run
+//     back to back on one XCD, so the image is fetched from HBM once and re-read from that XCD's L2.
+//   * the per-pixel table of the generic kernel (patch_embed.hip: 8 scalar 2-byte loads per LDS vector, every
+//     128-column tile of D re-gathering its tokens) is not touched on this path; tokenizers that are not tiles or
+//     strips (SFCEmbedding1D with other p / g, Peano at 27 px, ...) keep using the generic kernel.
+//
+// Replaces HilbertEmbedding1D / MortonEmbedding1D / RasterScan1DEmbedding .forward
+// (src/tokenizers/_1D/hilbert_embedding1D.py:30-44, morton_embedding1D.py:30-44, zigzag_embedding1D.py:30-39).
+#include "common_host.h"
+#include "device_common.h"
+#include <cstring>
+#include <vector>
+
+namespace sfcvit {
+namespace {
+
+constexpr int TM = 128, TN = 256, BK = 64, PT = 512;       // token rows, output columns, k per step, threads
+constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128;       // one LDS k-tile of each operand (128-byte rows)
+constexpr int MAXCLS = 8, DESC_HDR = 16;
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// W'[cls][d][c*256 + j] = W[d][perm[cls][j]*C + c]   (j = pixel of the tile in raster order, perm = its curve position)
+__global__ void pe2_permute_w_kernel(const uint16_t *__restrict__ w, const int32_t *__restrict__ perm, uint16_t *__restrict__ wp,
+                                     int D, int C, int ncls) {
+    const int K = C * 256;
+    const int64_t total = int64_t(ncls) * D * K;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int f = int(i % K), d = int((i / K) % D), cls = int(i / (int64_t(K) * D));
+        const int c = f >> 8, j = f & 255;
+        wp[i] = w[size_t(d) * K + perm[cls * 256 + j] * C + c];
+    }
+}
+
+struct RowInfo {              // one token row of the workgroup's tile
+    long long src;            // element offset of the tile origin in x (b * C*HW + origin[n])
+    int out_row;              // b * N + n, or -1 for a padding row
+    int pad;
+};
+
+template <bool XBF16>
+__global__ __launch_bounds__(PT) void pe2_fwd_kernel(const void *__restrict__ x, const int32_t *__restrict__ desc,
+                                                     const uint16_t *__restrict__ wp, const uint16_t *__restrict__ bias,
+                                                     uint16_t *__restrict__ y, int B, int C, int HW, int D, int n_row_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *abuf = smem, *bbuf = smem + 2 * A_BYTES;
+    RowInfo *rows = reinterpret_cast<RowInfo *>(smem + 2 * A_BYTES + 2 * B_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3;
+    const int K = C * 256, KT = K / BK, NCT = D / TN;
+    // XCD-aware tile order: the NCT column tiles of a row tile run consecutively on one XCD (blocks b, b + 8, ... share one)
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, ct = idx % NCT, rt = (idx / NCT) * 8 + xcd;
+    if (rt >= n_row_tiles) return;
+    const int mode_ncls = desc[1], kstep = desc[2], sstep = desc[3], N = desc[4];
+    const int32_t *toks = desc + DESC_HDR, *origin = desc + DESC_HDR + N;
+    // class of this row tile: every class is padded to whole tiles of TM rows
+    int cls = 0, tile0 = 0, cnt = 0, tok0 = 0;
+    for (int c = 0; c < mode_ncls; c++) {
+        const int t0 = desc[6 + c], n_c = desc[6 + c + 1] - t0, tiles_c = (n_c * B + TM - 1) / TM;
+        if (rt >= tile0 && rt < tile0 + tiles_c) { cls = c; cnt = n_c; tok0 = t0; break; }
+        tile0 += tiles_c;
+    }
+    if (tid < TM) {
+        const int ml = (rt - tile0) * TM + tid;                 // row within the class: (token index, image), image fastest
+        const bool valid = ml < cnt * B;
+        const int mc = valid ? ml : 0;
+        const int n = toks[tok0 + mc / B], b = mc % B;
+        rows[tid].src = (long long)(b) * C * HW + origin[n];
+        rows[tid].out_row = valid ? b * N + n : -1;
+    }
+    __syncthreads();
+
+    // --- staging through registers, TWO k-tiles deep ---------------------------------------------------------------
+    // A: this thread's 16-pixel row segment (row tid >> 2, segment tid & 3) of every k-tile; B: four 16-byte pieces of
+    // the W'[cls] panel.  Both are ordinary vector loads (no LDS-DMA), so hipcc's own counted vmcnt waits apply and a
+    // __syncthreads() is a bare barrier: the loads of k-tile t + 2 are issued before the MFMAs of k-tile t and are
+    // first touched two barriers later (128 KiB in flight per CU).  Measured at ViT-B / 256 images (profiles/r2): 160-168 us
+    // = 5.8 TB/s of operands into the CUs with one or with two k-tiles in flight -- the kernel is bound by operand
+    // delivery (786 KB per 128 x 256 tile: the fp32 segments and a W' panel that the streaming image pushes out of the
+    // 4 MiB L2: 403 MB memory-side fetch for 154 MB of image), not by latency; the generic kernel took 338 us + a 32 us cast.
+    const int arow = tid >> 2, aseg = tid & 3;
+    const long long asrc = rows[arow].src + aseg * sstep;
+    const int aw0 = arow * 128 + (((2 * aseg) ^ ((arow >> 1) & 7)) << 4), aw1 = arow * 128 + (((2 * aseg + 1) ^ ((arow >> 1) & 7)) << 4);
+    const uint16_t *wbase = wp + (size_t(cls) * D + size_t(ct) * TN) * K;
+    constexpr int NA = XBF16 ? 2 : 4;
+    struct Stage { u32x4 a[NA]; u32x4 b[4]; };
+    auto load_stage = [&](Stage &st, int kt) __attribute__((always_inline)) {
+        const long long off = asrc + (long long)(kt >> 2) * HW + (kt & 3) * kstep;
+        const u32x4 *pa = XBF16 ? reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(x) + off)
+                                : reinterpret_cast<const u32x4 *>(static_cast<const float *>(x) + off);
+        // (measured and not kept: non-temporal loads here -- twice the L2 requests, 168 -> 359 us)
+#pragma unroll
+        for (int i = 0; i < NA; i++) st.a[i] = pa[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int p = tid + PT * i, row = p >> 3, cs = p & 7;
+            st.b[i] = *reinterpret_cast<const u32x4 *>(wbase + size_t(row) * K + kt * BK + cs * 8);
+        }
+    };
+    auto write_stage = [&](const Stage &st, int buf) __attribute__((always_inline)) {
+        u32x4 lo, hi;
+        if (XBF16) {
+            lo = st.a[0]; hi = st.a[1];
+        } else {
+            const float *f = reinterpret_cast<const float *>(st.a);
+            lo = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+            hi = u32x4{pack2bf(f[8], f[9]), pack2bf(f[10], f[11]), pack2bf(f[12], f[13]), pack2bf(f[14], f[15])};
+        }
+        *reinterpret_cast<u32x4 *>(abuf + buf * A_BYTES + aw0) = lo;
+        *reinterpret_cast<u32x4 *>(abuf + buf * A_BYTES + aw1) = hi;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int p = tid + PT * i, row = p >> 3, cs = p & 7;
+            *reinterpret_cast<u32x4 *>(bbuf + buf * B_BYTES + row * 128 + ((cs ^ ((row >> 1) & 7)) << 4)) = st.b[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int cur) __attribute__((always_inline)) {
+        const char *ab = abuf + cur * A_BYTES + wr * 64 * 128, *bb = bbuf + cur * B_BYTES + wc * 64 * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) fa[i] = kc_frag(ab, 16 * i, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) fb[j] = kc_frag(bb, 16 * j, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    Stage s0, s1;                                     // s0: even k-tiles, s1: odd k-tiles (KT = 4 C is even)
+    load_stage(s0, 0);
+    load_stage(s1, 1);
+    write_stage(s0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+        // k-tile kt (buffer 0): s0 is free (written before the last barrier), s1 holds k-tile kt + 1
+        if (kt + 2 < KT) load_stage(s0, kt + 2);
+        compute(0);
+        write_stage(s1, 1);
+        __syncthreads();
+        // k-tile kt + 1 (buffer 1): s1 is free, s0 holds k-tile kt + 2
+        if (kt + 3 < KT) load_stage(s1, kt + 3);
+        compute(1);
+        if (kt + 2 < KT) write_stage(s0, 0);
+        __syncthreads();
+    }
+    mfma_fence();
+    // acc[i][j][r] = out[token row 64 wr + 16 i + (lane & 15)][column ct*TN + 64 wc + 16 j + 4 (lane >> 4) + r]
+    const int g = lane >> 4, li = lane & 15, col0 = ct * TN + 64 * wc + 4 * g;
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) bv[j][r] = bias ? bf2f(bias[col0 + 16 * j + r]) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int orow = rows[64 * wr + 16 * i + li].out_row;
+        if (orow < 0) continue;
+        uint16_t *dst = y + size_t(orow) * D + col0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32x2 o = {pack2bf(acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1]),
+                             pack2bf(acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3])};
+            *reinterpret_cast<u32x2 *>(dst + 16 * j) = o;
+        }
+    }
+}
+
+constexpr int PE2_LDS = 2 * A_BYTES + 2 * B_BYTES + TM * int(sizeof(RowInfo));
+
+}  // namespace
+
+// Eligibility + launch of the tiled forward.  -1: not eligible (the caller uses the generic kernel).
+int pe2_fwd(const sfcvit_patch_embed_args &a, hipStream_t s) {
+    if (!a.desc || a.P != 256 || a.D % TN || a.desc_ncls <= 0 || a.desc_ncls > MAXCLS) return -1;
+    const int K = a.C * 256;
+    const int64_t need = int64_t(a.desc_ncls) * a.D * K * 2;
+    if (!a.workspace || a.workspace_bytes < need) return -1;
+    if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.HW & 7)) return -1;
+    uint16_t *wp = static_cast<uint16_t *>(a.workspace);
+    hipLaunchKernelGGL(pe2_permute_w_kernel, dim3(1024), dim3(256), 0, s, static_cast<const uint16_t *>(a.w), a.desc + DESC_HDR + 2 * a.N,
+                       wp, a.D, a.C, a.desc_ncls);
+    if (int rc = check_launch("patch_embed_fwd (tiled) permute")) return rc;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pe2_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PE2_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&pe2_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PE2_LDS) != hipSuccess)
+            return check_launch("patch_embed_fwd (tiled) attribute");
+        attr = true;
+    }
+    int n_row_tiles = 0;
+    for (int c = 0; c < a.desc_ncls; c++) n_row_tiles += int((int64_t(a.desc_cnt[c]) * a.B + TM - 1) / TM);
+    const int NCT = a.D / TN;
+    const int groups = (n_row_tiles + 7) / 8;                       // row tiles are dealt to the 8 XCD slots in groups of 8
+    dim3 grid(unsigned(groups) * 8u * unsigned(NCT)), block(PT);
+    if (a.x_is_bf16)
+        hipLaunchKernelGGL(pe2_fwd_kernel<true>, grid, block, PE2_LDS, s, a.x, a.desc, wp, static_cast<const uint16_t *>(a.bias),
+                           static_cast<uint16_t *>(a.y), a.B, a.C, a.HW, a.D, n_row_tiles);
+    else
+        hipLaunchKernelGGL(pe2_fwd_kernel<false>, grid, block, PE2_LDS, s, a.x, a.desc, wp, static_cast<const uint16_t *>(a.bias),
+                           static_cast<uint16_t *>(a.y), a.B, a.C, a.HW, a.D, n_row_tiles);
+    return check_launch("patch_embed_fwd (tiled)");
+}
+
+}  // namespace sfcvit
+
+using namespace sfcvit;
+
+// HOST.  Analyses a pixel table (sfcvit_pixel_table output, host copy): if every token is a 16 x 16 pixel tile of the
+// image (any visiting order, <= 8 distinct pixel orders inside a tile) or a strip of 256 consecutive pixels, writes the
+// tile descriptor the tiled kernels take (layout below) and returns the number of int32 written; 0 = not tileable
+// (use the generic path); < 0 = error.  desc: [0] mode (1 tile, 2 strip) [1] classes [2] k-tile step [3] segment step
+// [4] N [5] 256 [6 .. 6+classes] first token (in `toks`) of each class, then N; [16 .. 16+N) token ids grouped by
+// class; [16+N .. 16+2N) pixel offset of each token's origin; then classes x 256 curve positions of the tile's pixels
+// in raster order.
+extern "C" int sfcvit_tile_descriptors(const int32_t *pix, int N, int P, int img_w, int32_t *desc, int capacity) {
+    if (!pix || !desc || N <= 0 || img_w <= 0) return fail(SFCVIT_EINVAL, "tile_descriptors: bad argument");
+    if (P != 256 || (img_w & 7)) return 0;
+    std::vector<int32_t> origin(N), cls(N);
+    std::vector<std::vector<int32_t>> perms;
+    bool strip = true;
+    for (int n = 0; n < N && strip; n++)
+        for (int k = 0; k < 256; k++)
+            if (pix[size_t(n) * 256 + k] != n * 256 + k) { strip = false; break; }
+    int mode = 0;
+    if (strip) {
+        mode = 2;
+        std::vector<int32_t> id(256);
+        for (int k = 0; k < 256; k++) id[k] = k;
+        perms.push_back(id);
+        for (int n = 0; n < N; n++) { origin[n] = n * 256; cls[n] = 0; }
+    } else {
+        mode = 1;
+        for (int n = 0; n < N; n++) {
+            const int32_t *pp = pix + size_t(n) * 256;
+            int r0 = 1 << 30, c0 = 1 << 30;
+            for (int k = 0; k < 256; k++) { r0 = std::min(r0, pp[k] / img_w); c0 = std::min(c0, pp[k] % img_w); }
+            if (c0 & 7) return 0;                                         // 16-byte vector loads of the row segments
+            std::vector<int32_t> pos(256, -1);
+            for (int k = 0; k < 256; k++) {
+                const int r = pp[k] / img_w - r0, c = pp[k] % img_w - c0;
+                if (r >= 16 || c >= 16 || pos[r * 16 + c] >= 0) return 0;   // not a 16 x 16 tile
+                pos[r * 16 + c] = k;
+            }
+            origin[n] = r0 * img_w + c0;
+            int found = -1;
+            for (size_t c = 0; c < perms.size(); c++)
+                if (perms[c] == pos) { found = int(c); break; }
+            if (found < 0) {
+                if (perms.size() >= size_t(MAXCLS)) return 0;
+                perms.push_back(pos);
+                found = int(perms.size()) - 1;
+            }
+            cls[n] = found;
+        }
+    }
+    const int ncls = int(perms.size());
+    const int total = DESC_HDR + 2 * N + ncls * 256;
+    if (capacity < total) return fail(SFCVIT_EINVAL, "tile_descriptors: capacity %d < %d", capacity, total);
+    std::memset(desc, 0, sizeof(int32_t) * DESC_HDR);
+    desc[0] = mode; desc[1] = ncls;
+    desc[2] = mode == 1 ? 4 * img_w : 64;          // k-tile = 4 tile rows of 16 pixels / 64 consecutive pixels
+    desc[3] = mode == 1 ? img_w : 16;              // segment = one tile row / 16 consecutive pixels
+    desc[4] = N; desc[5] = 256;
+    int t = 0;
+    for (int c = 0; c < ncls; c++) {
+        desc[6 + c] = t;
+        for (int n = 0; n < N; n++)
+            if (cls[n] == c) desc[DESC_HDR + t++] = n;
+    }
+    desc[6 + ncls] = t;
+    for (int n = 0; n < N; n++) desc[DESC_HDR + N + n] = origin[n];
+    for (int c = 0; c < ncls; c++)
+        for (int j = 0; j < 256; j++) desc[DESC_HDR + 2 * N + c * 256 + j] = perms[c][j];
+    return total;
+}

@@ -18,7 +18,8 @@ class PatchEmbedArgs(ctypes.Structure):
                 ("y", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("B", c_int32), ("C", c_int32), ("HW", c_int32), ("N", c_int32), ("P", c_int32),
-                ("D", c_int32), ("x_is_bf16", c_int32)]
+                ("D", c_int32), ("x_is_bf16", c_int32),
+                ("desc", c_void_p), ("desc_ncls", c_int32), ("desc_cnt", c_int32 * 8)]
 
 
 class GemmArgs(ctypes.Structure):
@@ -56,6 +57,7 @@ SIGNATURES = {
     "sfcvit_curve_table": (c_int, [c_int, c_int, c_void_p]),
     "sfcvit_curve_table_rc": (c_int, [c_int, c_int, c_void_p]),
     "sfcvit_pixel_table": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sfcvit_tile_descriptors": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int]),
     "sfcvit_patch_embed_fwd": (c_int, [ctypes.POINTER(PatchEmbedArgs), c_void_p]),
     "sfcvit_patch_embed_bwd": (c_int, [ctypes.POINTER(PatchEmbedArgs), c_void_p]),
     "sfcvit_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),

@@ -97,26 +97,35 @@ def _bgrad(dy2, b=None):
 # ----------------------------------------------------------------------------
 class _PatchEmbed(Function):
     @staticmethod
-    def forward(ctx, x, pix, w, b):
-        # The kernels round the pixels to bf16 when they load them; doing that once up front gives the same tokens bit
-        # for bit, halves the bytes both kernels pull through the texture path (they are bound by it: every
-        # 128-column tile of D re-reads its token tile) and halves what is kept for backward (77 instead of 154 MB).
-        x = _c(x if x.dtype == _BF16 else x.to(_BF16))
+    def forward(ctx, x, pix, w, b, desc):
+        tiled = desc is not None and pix.shape[1] == 256 and w.shape[0] % 256 == 0
+        if tiled:
+            # tiles / strips: the tiled kernel reads whole 16-pixel row segments of the image AS IT IS (fp32 from the
+            # loader: one pass over 154 MB at ViT-B / 256 images; a bf16 copy first would cost that pass plus its own
+            # write and re-read) and rounds to bf16 on the way into LDS -- the same rounding, the same tokens
+            x = _c(x)
+        else:
+            # The generic kernels round the pixels to bf16 when they load them; doing that once up front gives the same
+            # tokens bit for bit, halves the bytes both kernels pull through the texture path (they are bound by it: every
+            # 128-column tile of D re-reads its token tile) and halves what is kept for backward (77 instead of 154 MB).
+            x = _c(x if x.dtype == _BF16 else x.to(_BF16))
         ctx.save_for_backward(x, pix)
         ctx.D = w.shape[0]
         ctx.has_bias = b is not None
-        return ops.patch_embed_fwd(x, pix, w, b)
+        ctx.desc = desc if tiled else None
+        return ops.patch_embed_fwd(x, pix, w, b, ctx.desc)
 
     @staticmethod
     def backward(ctx, dy):
         x, pix = ctx.saved_tensors
-        dw, db = ops.patch_embed_bwd(x, pix, _c(dy), ctx.D, want_bias=ctx.has_bias)
-        return None, None, dw.to(_BF16), (db.to(_BF16) if db is not None else None)
+        dw, db = ops.patch_embed_bwd(x, pix, _c(dy), ctx.D, want_bias=ctx.has_bias, desc=ctx.desc)
+        return None, None, dw.to(_BF16), (db.to(_BF16) if db is not None else None), None
 
 
-def patch_embed(x, pix, weight, bias):
-    """Fused curve gather + patchify + projection: x [B,C,H,W] (fp32 or bf16) -> [B,N,D] bf16."""
-    return _PatchEmbed.apply(x, pix, _bf(weight), _bf(bias))
+def patch_embed(x, pix, weight, bias, desc=None):
+    """Fused curve gather + patchify + projection: x [B,C,H,W] (fp32 or bf16) -> [B,N,D] bf16.
+    desc = ops.TileDesc of the pixel table (tokens are 16 x 16 tiles / 256-pixel strips) or None."""
+    return _PatchEmbed.apply(x, pix, _bf(weight), _bf(bias), desc)
 
 
 # ----------------------------------------------------------------------------

@@ -334,6 +334,36 @@ def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0):
 # ----------------------------------------------------------------------------
 # tokenizer
 # ----------------------------------------------------------------------------
+class TileDesc:
+    """Device copy + host facts of a tile descriptor (sfcvit_tile_descriptors): the tokenizer's pixel table turned out
+    to be 16 x 16 pixel tiles (or 256-pixel strips), so the coalesced kernels of csrc/patch_embed_tiled.hip apply."""
+
+    def __init__(self, desc_host, device):
+        self.mode, self.ncls = int(desc_host[0]), int(desc_host[1])
+        self.cnt = [int(desc_host[6 + c + 1] - desc_host[6 + c]) for c in range(self.ncls)]
+        self.dev = torch.from_numpy(desc_host.copy()).to(device)
+
+
+def tile_descriptor(pix_host, img_w, device):
+    """pix_host: numpy int32 [N, P] (the host pixel table) -> TileDesc, or None when the tokens are not tiles / strips."""
+    import numpy as np
+    N, P = pix_host.shape
+    pix_host = np.ascontiguousarray(pix_host, dtype=np.int32)
+    cap = 16 + 2 * N + 8 * 256
+    out = np.zeros(cap, dtype=np.int32)
+    n = lib.sfcvit_tile_descriptors(ctypes.c_void_p(pix_host.ctypes.data), N, P, int(img_w), ctypes.c_void_p(out.ctypes.data), cap)
+    if n < 0:
+        check(n, "sfcvit_tile_descriptors")
+    return TileDesc(out[:n], device) if n > 0 else None
+
+
+def _pe_desc(a, desc):
+    if desc is not None:
+        a.desc, a.desc_ncls = desc.dev.data_ptr(), desc.ncls
+        for c, n in enumerate(desc.cnt):
+            a.desc_cnt[c] = n
+
+
 def _pe_args(x, pix, n_tokens, P, D):
     if not x.is_cuda:
         raise _lib.SfcvitError("patch_embed: the HIP path needs a CUDA (ROCm) tensor; there is no CPU fallback")
@@ -349,8 +379,9 @@ def _pe_args(x, pix, n_tokens, P, D):
     return a
 
 
-def patch_embed_fwd(x, pix, w, bias):
-    """x [B,C,H,W] fp32/bf16, pix [N,P] int32 (device), w [D, P*C] bf16 -> [B, N, D] bf16."""
+def patch_embed_fwd(x, pix, w, bias, desc=None):
+    """x [B,C,H,W] fp32/bf16, pix [N,P] int32 (device), w [D, P*C] bf16 -> [B, N, D] bf16.
+    desc: TileDesc (tile_descriptor) or None; with it the tiled kernel runs when P = 256 and D % 256 == 0."""
     N, P = pix.shape
     D = w.shape[0]
     _need(w, _BF16, "patch_embed w", 2)
@@ -360,12 +391,13 @@ def patch_embed_fwd(x, pix, w, bias):
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     a.w, a.y, a.workspace, a.workspace_bytes = w.data_ptr(), y.data_ptr(), ws.data_ptr(), nbytes
     a.bias = _need(bias, _BF16, "patch_embed bias", 1).data_ptr() if bias is not None else None
+    _pe_desc(a, desc)
     check(_launch("pe_fwd_kernel", 2.0 * a.B * N * P * a.C * D,
                   lambda: lib.sfcvit_patch_embed_fwd(ctypes.byref(a), _stream())), "sfcvit_patch_embed_fwd")
     return y
 
 
-def patch_embed_bwd(x, pix, dy, D, want_bias=True):
+def patch_embed_bwd(x, pix, dy, D, want_bias=True, desc=None):
     """-> dW fp32 [D, P*C], dbias fp32 [D]."""
     N, P = pix.shape
     _need(dy, _BF16, "patch_embed dy", 3)
@@ -376,6 +408,7 @@ def patch_embed_bwd(x, pix, dy, D, want_bias=True):
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     a.y, a.dw, a.dbias = dy.data_ptr(), dw.data_ptr(), (db.data_ptr() if want_bias else None)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    _pe_desc(a, desc)
     check(_launch("pe_bwd_kernel", 2.0 * a.B * N * P * a.C * D,
                   lambda: lib.sfcvit_patch_embed_bwd(ctypes.byref(a), _stream())), "sfcvit_patch_embed_bwd")
     return dw, db

@@ -44,6 +44,7 @@ class _FusedTokenizer(BasePatchEmbedding):
         self._geom = (img_size, pre_patch, group)
         self._pix = None
         self._pix_key = None
+        self._desc = None
         self.proj = nn.Linear(in_channels * pre_patch * pre_patch * group, embed_dim)
 
     def _flat_table(self):          # -> 1-D integer array of length grid*grid, or None for raster
@@ -63,7 +64,12 @@ class _FusedTokenizer(BasePatchEmbedding):
             img, p, g = self._geom
             grid = img // p
             flat = np.arange(grid * grid, dtype=np.int32) if buf is None else buf.detach().cpu().numpy()
-            self._pix = torch.from_numpy(_pixel_table(flat, img, p, g)).to(device)
+            pix_host = _pixel_table(flat, img, p, g)
+            self._pix = torch.from_numpy(pix_host).to(device)
+            # are the tokens 16 x 16 pixel tiles (Hilbert / Z at 256 pixels per token) or 256-pixel strips (raster)?  Then
+            # the coalesced kernels apply (csrc/patch_embed_tiled.hip); decided once, on the host, with the table
+            from .. import ops
+            self._desc = ops.tile_descriptor(pix_host, img, device) if torch.device(device).type == "cuda" else None
             self._pix_key = key
         return self._pix
 
@@ -71,7 +77,8 @@ class _FusedTokenizer(BasePatchEmbedding):
         img = self._geom[0]
         if x.dim() != 4 or x.shape[2] != img or x.shape[3] != img:
             raise ValueError(f"expected [B, C, {img}, {img}] input, got {tuple(x.shape)}")
-        return F.patch_embed(x, self._pix_table(x.device), self.proj.weight, self.proj.bias)
+        pix = self._pix_table(x.device)
+        return F.patch_embed(x, pix, self.proj.weight, self.proj.bias, self._desc)
 
 
 class _Curve1D(_FusedTokenizer):

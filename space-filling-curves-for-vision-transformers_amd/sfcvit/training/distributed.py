@@ -65,6 +65,13 @@ class GradReducer:
                 self._param_bucket[id(p)] = len(self.buckets) - 1
         for _, _, p in views:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self.world > 1:
+            # replicas must start identical: rank 0's parameters win (same-seed construction already gives that; a
+            # model built or loaded differently on some rank would otherwise drift silently)
+            dist.broadcast(self.opt.flat_param, src=0, group=self.group)
+            master = getattr(self.opt, "master", None)
+            if master is not None:
+                master.copy_(self.opt.flat_param)
 
     def begin_step(self):
         self._handles = []

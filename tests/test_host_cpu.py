@@ -282,3 +282,51 @@ def test_altvit_classes_have_the_reference_surface(golden_dir):
         assert abs(float(mod.pos_embedding.double().norm()) - gold[name]["pos_embedding_l2"]) < 1e-4 * gold[name]["pos_embedding_l2"]
     with pytest.raises(AssertionError, match="power of 2"):
         alt.HilbertViT(image_size=48, patch_size=4, num_classes=10, dim=64, depth=1, heads=1, mlp_dim=64)
+
+
+@pytest.mark.parametrize("curve,img,expect", [("hilbert", 224, (1, 4)), ("hilbert", 384, (1, 4)), ("hilbert", 32, (1, 3)),
+                                              ("z", 224, (1, 1)), ("z", 384, (1, 1)), ("raster", 224, (2, 1)), ("raster", 32, (2, 1))])
+def test_tile_descriptors_reconstruct_the_pixel_table(curve, img, expect):
+    """sfcvit_tile_descriptors (host): SURVEY App. A.5 as code -- at the BASELINE sizes every 256-pixel token of the
+    Hilbert / Z order is one 16 x 16 tile with one of <= 4 (Hilbert) / exactly 1 (Z) intra-tile pixel orders, a raster
+    token is a 256-pixel strip; the descriptor (origin per token, permutation per class) must reproduce the pixel
+    table the generic kernel uses, entry by entry (index work: exact)."""
+    import ctypes
+    from sfcvit._lib import lib
+    from sfcvit.tokenizers.embeddings import _pixel_table
+    from sfcvit.curves import curve_table, hilbert_curve, z_curve
+    flat = np.arange(img * img, dtype=np.int32) if curve == "raster" else curve_table({"hilbert": hilbert_curve, "z": z_curve}[curve], img)
+    pix = _pixel_table(flat, img, 1, 256)
+    N = pix.shape[0]
+    cap = 16 + 2 * N + 8 * 256
+    desc = np.zeros(cap, dtype=np.int32)
+    n = lib.sfcvit_tile_descriptors(ctypes.c_void_p(pix.ctypes.data), N, 256, img, ctypes.c_void_p(desc.ctypes.data), cap)
+    assert n == 16 + 2 * N + expect[1] * 256
+    mode, ncls = int(desc[0]), int(desc[1])
+    assert (mode, ncls) == expect and desc[4] == N
+    starts = desc[6:6 + ncls + 1]
+    assert starts[0] == 0 and starts[-1] == N
+    toks, origin = desc[16:16 + N], desc[16 + N:16 + 2 * N]
+    perm = desc[16 + 2 * N:n].reshape(ncls, 256)
+    assert sorted(toks.tolist()) == list(range(N))
+    j = np.arange(256)
+    local = (j // 16) * img + j % 16 if mode == 1 else j
+    for c in range(ncls):
+        assert sorted(perm[c].tolist()) == list(range(256))
+        for t in toks[starts[c]:starts[c + 1]]:
+            assert np.array_equal(pix[t][perm[c]], origin[t] + local)
+
+
+def test_tile_descriptors_decline_other_tokenizers():
+    import ctypes
+    from sfcvit._lib import lib
+    from sfcvit.tokenizers.embeddings import _pixel_table
+    from sfcvit.curves import curve_table, hilbert_curve
+    desc = np.zeros(16 + 2 * 4096 + 2048, dtype=np.int32)
+    # 64 pixels per token: not 256
+    pix = _pixel_table(curve_table(hilbert_curve, 32), 32, 1, 64)
+    assert lib.sfcvit_tile_descriptors(ctypes.c_void_p(pix.ctypes.data), pix.shape[0], 64, 32, ctypes.c_void_p(desc.ctypes.data), desc.size) == 0
+    # 256 pixels per token that are not one tile: 2 x 2 pre-patches grouped by 64 along the curve on a 64-px image
+    pix = _pixel_table(curve_table(hilbert_curve, 32), 64, 2, 64)
+    got = lib.sfcvit_tile_descriptors(ctypes.c_void_p(pix.ctypes.data), pix.shape[0], 256, 64, ctypes.c_void_p(desc.ctypes.data), desc.size)
+    assert got >= 0          # a 16 x 16 tile in a different pixel order is still a tile; anything else is declined (0)

@@ -4,6 +4,8 @@ Tolerances: outputs are bf16 (8 significant bits) of fp32-accumulated sums, so t
 bar is |err| <= 2^-7 * |ref| + a small absolute term scaled to the output's rms."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -522,3 +524,32 @@ def test_attention_bwd_fused_vs_two_kernel_form(ops, B, N, H, p, monkeypatch):
     ref = ((torch.softmax(s, -1) * mask) @ sp(v)).transpose(1, 2).reshape(B, N, D)
     ref.backward(dout.float())
     close(one, qf.grad, rel=1 / 48, abs_scale=1 / 24)
+
+
+@pytest.mark.parametrize("curve,img,D,B,xdt", [("hilbert", 224, 768, 3, torch.float32), ("hilbert", 224, 256, 130, torch.float32),
+                                               ("z", 384, 1024, 2, torch.float32), ("raster", 224, 768, 2, torch.bfloat16),
+                                               ("hilbert", 32, 256, 37, torch.float32), ("z", 32, 512, 4, torch.bfloat16)])
+def test_patch_embed_tiled_vs_generic_and_reference(ops, curve, img, D, B, xdt):
+    """The tiled gather + projection kernel (csrc/patch_embed_tiled.hip: 16-pixel row segments, class-permuted weight)
+    against the generic pixel-table kernel and against plain torch indexing with the SAME table: identical products,
+    another summation order (fp32 accumulate), so bf16-rounding-sized differences only.  Covers ragged class sizes
+    (rows padded to whole 128-row tiles), 1 / 3 / 4 classes, strips, fp32 and bf16 images."""
+    from sfcvit.tokenizers.embeddings import _pixel_table
+    from sfcvit.curves import curve_table, hilbert_curve, z_curve
+    g = torch.Generator(device="cuda").manual_seed(21)
+    flat = np.arange(img * img, dtype=np.int32) if curve == "raster" else curve_table({"hilbert": hilbert_curve, "z": z_curve}[curve], img)
+    pix_h = _pixel_table(flat, img, 1, 256)
+    pix = torch.from_numpy(pix_h).cuda()
+    desc = ops.tile_descriptor(pix_h, img, "cuda")
+    assert desc is not None
+    x = torch.randn(B, 3, img, img, device="cuda", generator=g).to(xdt)
+    w = bf(torch.randn(D, 768, device="cuda", generator=g) / 28)
+    b = bf(torch.randn(D, device="cuda", generator=g))
+    tiled = ops.patch_embed_fwd(x, pix, w, b, desc)
+    generic = ops.patch_embed_fwd(x.to(torch.bfloat16), pix, w, b, None)
+    close(tiled, generic.float(), rel=1 / 128, abs_scale=1 / 128)
+    tok = x.to(torch.bfloat16).float().reshape(B, 3, img * img)[:, :, pix.long()]       # [B, C, N, P]
+    tok = tok.permute(0, 2, 3, 1).reshape(B, pix.shape[0], 768)                           # feature = k*C + c
+    ref = tok @ w.float().t() + b.float()
+    close(tiled, ref, rel=1 / 100, abs_scale=1 / 100)
+    assert torch.equal(tiled, ops.patch_embed_fwd(x, pix, w, b, desc))
