@@ -164,6 +164,8 @@ typedef struct sfcvit_gemm_args {
                               separate pass over the stored bf16 C.  Needs workspace_bytes >=
                               sfcvit_gemm_colsum_workspace(M, N); not with split-K or fp32 C. */
     int32_t colsum_bf16;
+    const uint32_t *seed_off; /* NULL, or a device word added to dropout_seed when the kernel RUNS (sfcvit_step_advance):
+                                 lets a captured graph draw a new mask per replay */
 } sfcvit_gemm_args;
 
 int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);
@@ -206,7 +208,7 @@ int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const
  * bias gradient of the sub-layer's last Linear, for free in the same pass. */
 int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, const float *rstd,
                               const void *gamma, const void *dx_add, void *dx, void *dx_drop, float p,
-                              uint32_t seed, void *dgamma, void *dbeta, void *dcol, int grads_bf16, int M, int D,
+                              uint32_t seed, const uint32_t *seed_off, void *dgamma, void *dbeta, void *dcol, int grads_bf16, int M, int D,
                               void *ws, void *stream);
 /* grads_bf16 != 0: dgamma / dbeta / dcol are bf16 [D] instead of fp32 -- the caller passes views of its flat
  * gradient buffer and no cast / accumulate pass follows. */
@@ -230,6 +232,7 @@ typedef struct sfcvit_attn_args {
     float dropout_p;  /* > 0: dropout on the attention probabilities (SDPA dropout_p, training mode);
                          row = (b*H + h)*N + q, col = key of the mask function */
     uint32_t dropout_seed;
+    const uint32_t *seed_off; /* as in sfcvit_gemm_args */
 } sfcvit_attn_args;
 
 int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream);
@@ -243,8 +246,9 @@ int sfcvit_gelu_fwd(const void *x, void *y, int64_t n, void *stream);
 /* dx = dy * gelu'(x) */
 int sfcvit_gelu_bwd(const void *dy, const void *x, void *dx, int64_t n, void *stream);
 /* GELU followed by nn.Dropout(p) (MultiLayerPredictor, vit.py:308-309) on a [rows, cols] tensor, cols % 8 == 0. */
-int sfcvit_gelu_drop_fwd(const void *x, void *y, int rows, int cols, float p, uint32_t seed, void *stream);
-int sfcvit_gelu_drop_bwd(const void *dy, const void *x, void *dx, int rows, int cols, float p, uint32_t seed, void *stream);
+int sfcvit_gelu_drop_fwd(const void *x, void *y, int rows, int cols, float p, uint32_t seed, const uint32_t *seed_off, void *stream);
+int sfcvit_gelu_drop_bwd(const void *dy, const void *x, void *dx, int rows, int cols, float p, uint32_t seed, const uint32_t *seed_off,
+                         void *stream);
 /* The keep mask itself, as bf16 {0, 1/(1-p)} (tests and debugging): out [rows, cols]. */
 int sfcvit_dropout_mask(void *out, int64_t rows, int cols, float p, uint32_t seed, void *stream);
 
@@ -276,8 +280,17 @@ typedef struct sfcvit_adamw_args {
     float grad_scale;  /* every gradient (and the norm) is multiplied by this first:
                           1/world_size after a SUM all-reduce, else 1 */
     int32_t step;      /* 1-based */
+    const float *dev_state; /* NULL, or the device step state of sfcvit_step_advance: lr and the bias corrections are then
+                               read from it when the kernel RUNS (lr / step above are ignored) */
 } sfcvit_adamw_args;
 int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream);
+
+/* Device-resident step state, 8 words (16-byte aligned): [0] dropout seed offset (uint32), [1] step (int32), [2] learning
+ * rate (float, host-written), [3] 1 - beta1^step, [4] 1 / sqrt(1 - beta2^step).  sfcvit_step_advance increments the step
+ * and refreshes [0], [3], [4]; run it once per training step before the forward (first node of a captured step).  The
+ * reference keeps all of this on the host (torch.optim.AdamW's step counter, torch's Philox offset); on the device a
+ * whole training step replays from one hipGraph (main.py:284's torch.compile(mode="reduce-overhead") intent). */
+int sfcvit_step_advance(void *state, float beta1, float beta2, uint32_t seed_base, void *stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(const sfcvit_attn_arg
     const uint32_t dth = drop_thresh(a.dropout_p);
     const float dsc = 1.f / (1.f - a.dropout_p);
     // mask row of this lane's query
-    const uint32_t drk = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q0 + (lane & 15)));
+    const uint32_t drk = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q0 + (lane & 15)));
 
     bf16x8 qf[2];
     qf[0] = global_frag(qp, ld, q0, N, 0, lane);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(const sfcvit_attn_
                     float keep = 1.f;
                     if (drop) {
                         bool k0b, k1b;
-                        drop_keep2(drop_row_key(a.dropout_seed, dbh + uint64_t(q0 + ql)), uint32_t(dkey >> 1), dth, k0b, k1b);
+                        drop_keep2(drop_row_key(eff_seed(a.dropout_seed, a.seed_off), dbh + uint64_t(q0 + ql)), uint32_t(dkey >> 1), dth, k0b, k1b);
                         keep = ((dkey & 1) ? k1b : k0b) ? dsc : 0.f;
                     }
                     p[t][r] = pv * keep;                                   // dropped probabilities feed dV
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(const sfcvit_attn_a
     const bool drop = a.dropout_p > 0.f;
     const uint32_t dth = drop_thresh(a.dropout_p);
     const float dsc = 1.f / (1.f - a.dropout_p);
-    const uint32_t drk = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
+    const uint32_t drk = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
 
     bf16x8 qf[2], dof[2];
 #pragma unroll

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     for (int i = tid; i < npad; i += FT) {
         lse_s[i] = i < N ? lse[i] * 1.4426950408889634f : INFINITY;   // padded queries: p = exp2(-inf) = 0
         del_s[i] = i < N ? del[i] : 0.f;
-        rkey_s[i] = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(i));
+        rkey_s[i] = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(i));
     }
     {   // exchange rows no key wave writes (keys 16 nf .. npad - 1), both halves of the double buffer
         const int nz = (npad - 16 * nf) * 4;         // 16-byte pieces per half

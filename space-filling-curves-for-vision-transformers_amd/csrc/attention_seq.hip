@@ -112,7 +112,7 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_a
         mx = group_max(mx);                              // max of the RAW scores (scale > 0)
         const float mc = mx * c2;
         float l = 0.f;
-        const uint32_t drk = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
+        const uint32_t drk = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
 #pragma unroll
         for (int kf = 0; kf < MAXF; kf++)
             if (kf < nf) {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_seq_bwd_kv_kernel(const sfcvi
     for (int i = tid; i < npad; i += THREADS) {
         lse_s[i] = i < N ? lse[i] * 1.4426950408889634f : INFINITY;   // padded queries: p = exp2(-inf) = 0
         del_s[i] = i < N ? del[i] : 0.f;
-        rkey_s[i] = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(i));
+        rkey_s[i] = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(i));
     }
     __syncthreads();
     const int nf = NFC ? NFC : (N + 15) >> 4, nc = NFC ? ((NFC + 1) >> 1) : npad >> 5;   // npad = 32 nc here
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_bwd_q_kernel(const sfcvit
         if (qf >= nf) break;                             // wave-uniform
         const int q = 16 * qf + (lane & 15);
         const float lse_q = lse_a[o], del_q = del_a[o];
-        const uint32_t drk = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
+        const uint32_t drk = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
         const bf16x8 (&qfr)[2] = qfa[o];
         const bf16x8 (&dof)[2] = dofa[o];
         f32x4 dq[4];

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(THREADS) void attn_wide_fwd_kernel(const sfcvit_att
         mx = group_max(mx);
         const float mc = mx * c2;
         float l = 0.f;
-        const uint32_t drk = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
+        const uint32_t drk = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
 #pragma unroll
         for (int kf = 0; kf < MAXF; kf++)
             if (kf < nf) {
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(THREADS) void attn_wide_bwd_kv_kernel(const sfcvit_
     for (int i = tid; i < npad; i += THREADS) {
         lse_s[i] = i < N ? lse[i] * 1.4426950408889634f : INFINITY;
         del_s[i] = i < N ? del[i] : 0.f;
-        rkey_s[i] = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(i));
+        rkey_s[i] = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(i));
     }
     __syncthreads();
     const int nf = (N + 15) >> 4, nc = npad >> 5;          // npad % 32 == 0 here
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(THREADS) void attn_wide_bwd_q_kernel(const sfcvit_a
         const int q = 16 * qf + (lane & 15);
         const float lse_q = q < N ? a.lse[(size_t(b) * a.H + h) * N + q] * 1.4426950408889634f : 0.f;
         const float del_q = q < N ? a.delta[(size_t(b) * a.H + h) * N + q] : 0.f;
-        const uint32_t drk = drop_row_key(a.dropout_seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
+        const uint32_t drk = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
         bf16x8 qfr[S][2], dof[S][2];
 #pragma unroll
         for (int sl = 0; sl < S; sl++)

@@ -90,6 +90,10 @@ __device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row_key, uint32_t pa
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
     return x;
 }
+// Effective seed of a dropout site: the by-value seed of the call plus the device-resident per-step offset (NULL = 0).
+// With the offset a captured hipGraph draws fresh masks on every replay (sfcvit_step_advance moves the offset), and
+// forward and backward of one step still agree (both read it between two advances).
+__device__ __forceinline__ uint32_t eff_seed(uint32_t seed, const uint32_t *off) { return off ? seed + *off : seed; }
 __device__ __forceinline__ uint32_t drop_thresh(float p) { return uint32_t(p * 65536.f + 0.5f); }
 // keep flags of the two elements (cols 2*pair, 2*pair+1) of a row
 __device__ __forceinline__ void drop_keep2(uint32_t row_key, uint32_t pair_in_row, uint32_t thresh, bool &k0, bool &k1) {

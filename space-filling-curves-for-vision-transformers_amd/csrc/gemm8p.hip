@@ -350,7 +350,8 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
 
     const uint32_t thresh = (MASK & DROP) ? drop_thresh(g.dropout_p) : 0u;
     const float keep_scale = (MASK & DROP) ? 1.f / (1.f - g.dropout_p) : 1.f;
-    const uint32_t rk_in0 = (MASK & DROP) ? mix32(g.dropout_seed) : 0u, rk_in1 = (MASK & DROP) ? mix32(g.dropout_seed ^ 0x7FEB352Du) : 0u;
+    const uint32_t seed_e = (MASK & DROP) ? eff_seed(g.dropout_seed, g.seed_off) : 0u;
+    const uint32_t rk_in0 = (MASK & DROP) ? mix32(seed_e) : 0u, rk_in1 = (MASK & DROP) ? mix32(seed_e ^ 0x7FEB352Du) : 0u;
     const float dact_scale = g.dact_scale != 0.f ? g.dact_scale : 1.f;
     auto draw = [&]() __attribute__((always_inline)) {        // wave group 0, before its epilogue (tid 0 is in it)
         if (tid == 0) {

@@ -140,7 +140,7 @@ __device__ __forceinline__ void epilogue_vec(const sfcvit_gemm_args &g, int m, i
     if (g.dropout_p > 0.f) {
         const uint32_t th = drop_thresh(g.dropout_p);
         const float sc = 1.f / (1.f - g.dropout_p);
-        const uint32_t rk = drop_row_key(g.dropout_seed, uint64_t(m) + uint64_t(uint32_t(g.row_offset)));
+        const uint32_t rk = drop_row_key(eff_seed(g.dropout_seed, g.seed_off), uint64_t(m) + uint64_t(uint32_t(g.row_offset)));
 #pragma unroll
         for (int q = 0; q < NV / 2; q++) {
             bool k0, k1;

@@ -89,8 +89,10 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                                                          const float *__restrict__ mean, const float *__restrict__ rstd,
                                                          const uint16_t *__restrict__ gamma,
                                                          const uint16_t *__restrict__ dx_add, uint16_t *__restrict__ dx,
-                                                         uint16_t *__restrict__ dx_drop, float drop_p, uint32_t drop_seed,
+                                                         uint16_t *__restrict__ dx_drop, float drop_p, uint32_t drop_seed_arg,
+                                                         const uint32_t *__restrict__ seed_off,
                                                          float *__restrict__ partial, int M, int D) {
+    const uint32_t drop_seed = eff_seed(drop_seed_arg, seed_off);
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [WAVES][3][D] fp32
     const uint32_t drop_th = drop_thresh(drop_p);
     const float drop_sc = 1.f / (1.f - drop_p);
@@ -361,7 +363,8 @@ __global__ __launch_bounds__(THREADS) void gelu_kernel(const uint16_t *__restric
 template <bool BWD>
 __global__ __launch_bounds__(THREADS) void gelu_drop_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
                                                             uint16_t *__restrict__ out, int rows, int cols, float p,
-                                                            uint32_t seed) {
+                                                            uint32_t seed_arg, const uint32_t *__restrict__ seed_off) {
+    const uint32_t seed = eff_seed(seed_arg, seed_off);
     const uint32_t th = drop_thresh(p);
     const float sc = 1.f / (1.f - p);
     const int vpr = cols >> 3;
@@ -499,7 +502,12 @@ __device__ __forceinline__ void adamw_one(float &w, float &m, float &v, float gr
     w -= (a.lr / bc1) * (m / denom);
 }
 
-__global__ __launch_bounds__(THREADS) void adamw_kernel(const sfcvit_adamw_args a, float bc1, float rbc2) {
+__global__ __launch_bounds__(THREADS) void adamw_kernel(sfcvit_adamw_args a, float bc1, float rbc2) {
+    if (a.dev_state) {            // learning rate and bias corrections of THIS step from the device (sfcvit_step_advance)
+        a.lr = a.dev_state[2];
+        bc1 = a.dev_state[3];
+        rbc2 = a.dev_state[4];
+    }
     float gmul = a.grad_scale;
     if (a.sumsq) {
         const float norm = sqrtf(*a.sumsq) * a.grad_scale;
@@ -580,8 +588,8 @@ extern "C" int64_t sfcvit_layernorm_bwd_ws(int M, int D) {
 
 extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, const float *rstd,
                                          const void *gamma, const void *dx_add, void *dx, void *dx_drop, float p,
-                                         uint32_t seed, void *dgamma, void *dbeta, void *dcol, int grads_bf16, int M,
-                                         int D, void *ws, void *stream) {
+                                         uint32_t seed, const uint32_t *seed_off, void *dgamma, void *dbeta, void *dcol,
+                                         int grads_bf16, int M, int D, void *ws, void *stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !ws)
         return fail(SFCVIT_EINVAL, "layernorm_bwd: null pointer");
     if (M <= 0 || D <= 0 || D % 8 || D > 2048) return fail(SFCVIT_EINVAL, "layernorm_bwd: M=%d D=%d (D %% 8 == 0, D <= 2048)", M, D);
@@ -600,9 +608,9 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     auto *dxp = static_cast<uint16_t *>(dx);
     auto *ddp = static_cast<uint16_t *>(dx_drop);
     float *part = static_cast<float *>(ws);
-    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
-    else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
-    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, part, M, D);
+    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D);
+    else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D);
+    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D);
     if (int rc = check_launch("layernorm_bwd")) return rc;
     hipLaunchKernelGGL(ln_bwd_reduce, dim3((3 * D + 15) / 16), dim3(256), 0, s, part, dgamma, dbeta, dcol, nb, D, grads_bf16);
     return check_launch("layernorm_bwd_reduce");
@@ -611,7 +619,7 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
 extern "C" int sfcvit_layernorm_bwd(const void *dy, const void *x, const float *mean, const float *rstd,
                                     const void *gamma, const void *dx_add, void *dx, float *dgamma, float *dbeta,
                                     int M, int D, void *ws, void *stream) {
-    return sfcvit_layernorm_bwd_drop(dy, x, mean, rstd, gamma, dx_add, dx, nullptr, 0.f, 0u, dgamma, dbeta, nullptr, 0, M, D, ws, stream);
+    return sfcvit_layernorm_bwd_drop(dy, x, mean, rstd, gamma, dx_add, dx, nullptr, 0.f, 0u, nullptr, dgamma, dbeta, nullptr, 0, M, D, ws, stream);
 }
 
 namespace {
@@ -689,21 +697,22 @@ static int gelu_drop_check(const void *x, const void *y, int rows, int cols, flo
     return SFCVIT_OK;
 }
 
-extern "C" int sfcvit_gelu_drop_fwd(const void *x, void *y, int rows, int cols, float p, uint32_t seed, void *stream) {
+extern "C" int sfcvit_gelu_drop_fwd(const void *x, void *y, int rows, int cols, float p, uint32_t seed, const uint32_t *seed_off,
+                                    void *stream) {
     if (int rc = gelu_drop_check(x, y, rows, cols, p, "gelu_drop_fwd")) return rc;
     hipLaunchKernelGGL(gelu_drop_kernel<false>, dim3(grid_for(int64_t(rows) * cols / 8)), dim3(THREADS), 0,
                        static_cast<hipStream_t>(stream), static_cast<const uint16_t *>(nullptr),
-                       static_cast<const uint16_t *>(x), static_cast<uint16_t *>(y), rows, cols, p, seed);
+                       static_cast<const uint16_t *>(x), static_cast<uint16_t *>(y), rows, cols, p, seed, seed_off);
     return check_launch("gelu_drop_fwd");
 }
 
 extern "C" int sfcvit_gelu_drop_bwd(const void *dy, const void *x, void *dx, int rows, int cols, float p, uint32_t seed,
-                                    void *stream) {
+                                    const uint32_t *seed_off, void *stream) {
     if (!dy) return fail(SFCVIT_EINVAL, "gelu_drop_bwd: null pointer");
     if (int rc = gelu_drop_check(x, dx, rows, cols, p, "gelu_drop_bwd")) return rc;
     hipLaunchKernelGGL(gelu_drop_kernel<true>, dim3(grid_for(int64_t(rows) * cols / 8)), dim3(THREADS), 0,
                        static_cast<hipStream_t>(stream), static_cast<const uint16_t *>(dy), static_cast<const uint16_t *>(x),
-                       static_cast<uint16_t *>(dx), rows, cols, p, seed);
+                       static_cast<uint16_t *>(dx), rows, cols, p, seed, seed_off);
     return check_launch("gelu_drop_bwd");
 }
 
@@ -740,7 +749,7 @@ extern "C" int sfcvit_sumsq_accum(const void *g, int64_t n, int is_f32, float *o
 
 extern "C" int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream) {
     if (!a || !a->param || !a->master || !a->grad || !a->m || !a->v) return fail(SFCVIT_EINVAL, "adamw: null pointer");
-    if (a->n <= 0 || a->step < 1) return fail(SFCVIT_EINVAL, "adamw: n=%lld step=%d", (long long)a->n, a->step);
+    if (a->n <= 0 || (a->step < 1 && !a->dev_state)) return fail(SFCVIT_EINVAL, "adamw: n=%lld step=%d", (long long)a->n, a->step);
     const float bc1 = 1.f - powf(a->beta1, float(a->step));
     const float bc2 = 1.f - powf(a->beta2, float(a->step));
     if (!aligned16(a->param) || !aligned16(a->master) || !aligned16(a->grad) || !aligned16(a->m) || !aligned16(a->v))
@@ -748,4 +757,32 @@ extern "C" int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream) {
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((a->n + 7) / 8)), dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a, bc1,
                        1.f / sqrtf(bc2));
     return check_launch("adamw");
+}
+
+// ---------------------------------------------------------------------------
+// Device-resident step state: [0] dropout seed offset (uint32)  [1] step count (int32)  [2] learning rate (float,
+// written by the host, read by adamw)  [3] 1 - beta1^step  [4] 1 / sqrt(1 - beta2^step).  One thread advances it once
+// per training step -- as the first node of a captured step graph, so that every replay draws new dropout masks and
+// applies the right Adam bias correction without any by-value kernel argument changing.
+// ---------------------------------------------------------------------------
+namespace sfcvit {
+namespace {
+__global__ void step_advance_kernel(uint32_t *state, float beta1, float beta2, uint32_t seed_base) {
+    if (threadIdx.x || blockIdx.x) return;
+    const int step = int(state[1]) + 1;
+    state[1] = uint32_t(step);
+    state[0] = mix32(seed_base ^ (uint32_t(step) * 0x9E3779B1u));
+    float *f = reinterpret_cast<float *>(state);
+    f[3] = 1.f - powf(beta1, float(step));
+    f[4] = 1.f / sqrtf(1.f - powf(beta2, float(step)));
+}
+}  // namespace
+}  // namespace sfcvit
+
+extern "C" int sfcvit_step_advance(void *state, float beta1, float beta2, uint32_t seed_base, void *stream) {
+    using namespace sfcvit;
+    if (!state || !aligned16(state)) return fail(SFCVIT_EINVAL, "step_advance: state must be a 16-byte aligned device buffer of 8 words");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<uint32_t *>(state), beta1,
+                       beta2, seed_base);
+    return check_launch("step_advance");
 }

@@ -31,14 +31,14 @@ class GemmArgs(ctypes.Structure):
                 ("c_is_f32", c_int32), ("splitk", c_int32), ("workspace", c_void_p),
                 ("workspace_bytes", c_int64), ("force_generic", c_int32),
                 ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("dact_scale", c_float),
-                ("row_offset", c_int32), ("colsum_out", c_void_p), ("colsum_bf16", c_int32)]
+                ("row_offset", c_int32), ("colsum_out", c_void_p), ("colsum_bf16", c_int32), ("seed_off", c_void_p)]
 
 
 class AttnArgs(ctypes.Structure):
     _fields_ = [("qkv", c_void_p), ("out", c_void_p), ("lse", c_void_p), ("dout", c_void_p),
                 ("dqkv", c_void_p), ("delta", c_void_p),
                 ("B", c_int32), ("N", c_int32), ("H", c_int32), ("hd", c_int32), ("scale", c_float),
-                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32)]
+                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("seed_off", c_void_p)]
 
 
 class AdamWArgs(ctypes.Structure):
@@ -46,7 +46,7 @@ class AdamWArgs(ctypes.Structure):
                 ("v", c_void_p), ("sumsq", c_void_p), ("n", c_int64),
                 ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
                 ("weight_decay", c_float), ("max_norm", c_float), ("grad_scale", c_float),
-                ("step", c_int32)]
+                ("step", c_int32), ("dev_state", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/sfcvit.h declares.
@@ -73,11 +73,12 @@ SIGNATURES = {
     "sfcvit_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sfcvit_layernorm_bwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_float, ctypes.c_uint32, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_float, ctypes.c_uint32, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sfcvit_layernorm_bwd_ws": (c_int64, [c_int, c_int]),
-    "sfcvit_gelu_drop_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p]),
-    "sfcvit_gelu_drop_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p]),
+    "sfcvit_gelu_drop_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p, c_void_p]),
+    "sfcvit_gelu_drop_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint32, c_void_p, c_void_p]),
+    "sfcvit_step_advance": (c_int, [c_void_p, c_float, c_float, ctypes.c_uint32, c_void_p]),
     "sfcvit_dropout_mask": (c_int, [c_void_p, c_int64, c_int, c_float, ctypes.c_uint32, c_void_p]),
     "sfcvit_attention_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "sfcvit_attention_bwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),

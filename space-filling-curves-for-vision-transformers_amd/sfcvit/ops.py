@@ -130,9 +130,35 @@ def auto_splitk(M, N, K):
     return best
 
 
+# Device-resident step state (include/sfcvit.h, sfcvit_step_advance): None = seeds and Adam's step count live on the host
+# (the default, as in the reference); a CUDA int32[8] tensor = every dropout site adds the device seed offset and AdamW
+# reads lr / bias corrections from the device, so a whole training step can replay from one hipGraph
+# (sfcvit.training.GraphedTrainStep).
+STEP_STATE = None
+
+
+def _seed_off():
+    return ctypes.c_void_p(STEP_STATE.data_ptr()) if STEP_STATE is not None else None
+
+
+_site = 0     # device-state mode: dropout sites of the current step drawn so far
+
+
+def step_advance(state, beta1, beta2, seed_base):
+    global _site
+    _site = 0
+    check(lib.sfcvit_step_advance(_p(state), beta1, beta2, seed_base & 0xFFFFFFFF, _stream()), "sfcvit_step_advance")
+
+
 def next_seed():
     """32-bit dropout seed drawn on the host from torch's default CPU generator: reproducible under
     torch.manual_seed, no device synchronisation (kernels receive it as a plain argument)."""
+    global _site
+    if STEP_STATE is not None:
+        # device-state mode: the by-value seed only tells the sites of one step apart (it is frozen into a captured graph);
+        # what changes from step to step is the device offset the kernels add to it
+        _site += 1
+        return ((_site * 0x9E3779B1) & 0x7FFFFFFF) | 1
     return int(torch.randint(0, 0x7FFFFFFF, (), dtype=torch.int64)) * 2 + 1
 
 
@@ -173,6 +199,8 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
     args.a_kmajor, args.b_kmajor = int(a_kmajor), int(b_kmajor)
     args.act, args.dact, args.c_is_f32 = act, dact, int(out_f32)
     args.dropout_p, args.dropout_seed, args.dact_scale = dropout_p, dropout_seed, dact_scale
+    if dropout_p > 0.0 and STEP_STATE is not None:
+        args.seed_off = STEP_STATE.data_ptr()
     args.row_offset = row_offset
     plain = (bias is None and residual is None and aux_in is None and not want_aux and act == 0 and dact == 0
              and dropout_p == 0.0)
@@ -274,7 +302,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0
     if want_colsum:
         dcol = given[2] if given[2] is not None else torch.empty(D, device=x.device, dtype=gdt)
     check(lib.sfcvit_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_add), _p(dx), _p(dx_drop),
-                                        drop_p, drop_seed, _p(dg), _p(db), _p(dcol), int(gdt == _BF16), M, D, _p(ws),
+                                        drop_p, drop_seed, _seed_off() if drop_p > 0 else None, _p(dg), _p(db), _p(dcol),
+                                        int(gdt == _BF16), M, D, _p(ws),
                                         _stream()),
           "sfcvit_layernorm_bwd")
     out = (dx, dg, db) + ((dx_drop,) if drop_p > 0 else ()) + ((dcol,) if want_colsum else ())
@@ -310,6 +339,8 @@ def attention_fwd(qkv, n_heads, dropout_p=0.0, dropout_seed=0):
     a.qkv, a.out, a.lse = qkv.data_ptr(), out.data_ptr(), lse.data_ptr()
     a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
     a.dropout_p, a.dropout_seed = dropout_p, dropout_seed
+    if dropout_p > 0.0 and STEP_STATE is not None:
+        a.seed_off = STEP_STATE.data_ptr()
     check(_launch("attn_fwd_kernel", 4.0 * B * n_heads * N * N * hd,
                   lambda: lib.sfcvit_attention_fwd(ctypes.byref(a), _stream())), "sfcvit_attention_fwd")
     return out, lse
@@ -326,6 +357,8 @@ def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0):
     a.dqkv, a.delta = dqkv.data_ptr(), delta.data_ptr()
     a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
     a.dropout_p, a.dropout_seed = dropout_p, dropout_seed
+    if dropout_p > 0.0 and STEP_STATE is not None:
+        a.seed_off = STEP_STATE.data_ptr()
     check(_launch("attn_bwd", 10.0 * B * n_heads * N * N * hd,
                   lambda: lib.sfcvit_attention_bwd(ctypes.byref(a), _stream())), "sfcvit_attention_bwd")
     return dqkv
@@ -435,7 +468,7 @@ def gelu_bwd(dy, x):
 def gelu_drop_fwd(x, p, seed):
     _need(x, _BF16, "gelu_drop x", 2)
     y = torch.empty_like(x)
-    check(lib.sfcvit_gelu_drop_fwd(_p(x), _p(y), x.shape[0], x.shape[1], p, seed, _stream()), "sfcvit_gelu_drop_fwd")
+    check(lib.sfcvit_gelu_drop_fwd(_p(x), _p(y), x.shape[0], x.shape[1], p, seed, _seed_off(), _stream()), "sfcvit_gelu_drop_fwd")
     return y
 
 
@@ -443,7 +476,8 @@ def gelu_drop_bwd(dy, x, p, seed):
     _need(x, _BF16, "gelu_drop x", 2)
     _need(dy, _BF16, "gelu_drop dy", 2)
     dx = torch.empty_like(x)
-    check(lib.sfcvit_gelu_drop_bwd(_p(dy), _p(x), _p(dx), x.shape[0], x.shape[1], p, seed, _stream()), "sfcvit_gelu_drop_bwd")
+    check(lib.sfcvit_gelu_drop_bwd(_p(dy), _p(x), _p(dx), x.shape[0], x.shape[1], p, seed, _seed_off(), _stream()),
+          "sfcvit_gelu_drop_bwd")
     return dx
 
 
@@ -476,7 +510,7 @@ def sumsq_accum(g, out):
 
 
 def adamw_step(param, master, grad, m, v, sumsq, *, lr, beta1, beta2, eps, weight_decay, max_norm, step,
-               grad_scale=1.0):
+               grad_scale=1.0, dev_state=None):
     a = _lib.AdamWArgs()
     a.param, a.master, a.grad, a.m, a.v = (param.data_ptr(), master.data_ptr(), grad.data_ptr(),
                                            m.data_ptr(), v.data_ptr())
@@ -484,4 +518,6 @@ def adamw_step(param, master, grad, m, v, sumsq, *, lr, beta1, beta2, eps, weigh
     a.n = param.numel()
     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.max_norm, a.step = lr, beta1, beta2, eps, weight_decay, max_norm, step
     a.grad_scale = grad_scale
+    if dev_state is not None:
+        a.dev_state = dev_state.data_ptr()
     check(lib.sfcvit_adamw_step(ctypes.byref(a), _stream()), "sfcvit_adamw_step")

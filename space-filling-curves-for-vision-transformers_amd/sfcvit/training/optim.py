@@ -111,6 +111,8 @@ class FusedAdamW(FlatGradBuffer):
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
         self.master = self.m = self.v = self._sumsq = None
+        self.dev_state = None            # use_device_state(): int32[8] device tensor (include/sfcvit.h, sfcvit_step_advance)
+        self._seed_base = 0
 
     @property
     def lr(self):
@@ -119,6 +121,26 @@ class FusedAdamW(FlatGradBuffer):
     @lr.setter
     def lr(self, value):
         self.param_groups[0]["lr"] = value
+        if self.dev_state is not None:
+            self.dev_state.view(torch.float32)[2].fill_(float(value))      # stream-ordered, no host sync
+
+    def use_device_state(self, device=None, seed_base=None):
+        """Move the per-step scalars to the device: Adam's step count and bias corrections, the learning rate, and an
+        offset every dropout site adds to its seed.  `advance()` (one tiny kernel) then replaces the host-side
+        `step_count += 1` / fresh seeds, so a captured training step is replayable (GraphedTrainStep)."""
+        if self.dev_state is None:
+            if device is None:
+                device = self.params[0].device
+            self.dev_state = torch.zeros(8, device=device, dtype=torch.int32)
+            self.dev_state[1] = self.step_count
+            self._seed_base = int(torch.randint(0, 0x7FFFFFFF, (), dtype=torch.int64)) if seed_base is None else int(seed_base)
+            self.lr = self.lr                                               # writes state[2]
+        ops.STEP_STATE = self.dev_state
+        return self.dev_state
+
+    def advance(self):
+        """Device-state mode: begin a training step (step += 1, new dropout seed offset, bias corrections)."""
+        ops.step_advance(self.dev_state, self.betas[0], self.betas[1], self._seed_base)
 
     def _check(self, p):
         if p.dtype != torch.bfloat16 or not p.is_cuda:
@@ -136,7 +158,8 @@ class FusedAdamW(FlatGradBuffer):
             self._build()
         else:
             self.adopt_all()
-        self.step_count += 1
+        if self.dev_state is None:
+            self.step_count += 1         # device-state mode: advance() counts (and GraphedTrainStep mirrors it here)
         sumsq = None
         if self.max_grad_norm is not None:
             self._sumsq.zero_()
@@ -145,7 +168,7 @@ class FusedAdamW(FlatGradBuffer):
         ops.adamw_step(self.flat_param, self.master, self.flat_grad, self.m, self.v, sumsq,
                        lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
                        weight_decay=self.weight_decay, max_norm=self.max_grad_norm or 0.0,
-                       step=self.step_count, grad_scale=self.grad_scale)
+                       step=max(1, self.step_count), grad_scale=self.grad_scale, dev_state=self.dev_state)
 
     def grad_norm(self):
         """Total gradient norm of the last step (device tensor; no sync)."""

@@ -452,3 +452,43 @@ def test_shared_parameter_gradient_accumulates_once_per_use():
             assert float(torch.dot(g, r) / (g.norm() * r.norm())) >= 0.999
             assert abs(float(g.norm() / r.norm()) - 1) <= 2e-2
         assert w.grad.data_ptr() == opt.flat_grad.data_ptr() + 2 * opt.offsets[0]
+
+
+def test_graphed_train_step_replays_bit_exactly_and_draws_new_masks():
+    """GraphedTrainStep: the whole training step (training mode: dropout 0.1 / 0.5 on) captured into one hipGraph with
+    the step state on the device (sfcvit_step_advance) must take the SAME steps as the same code run eagerly in
+    device-state mode -- bit for bit, over warm-up + replays -- and two replays must not reuse a dropout mask."""
+    from sfcvit import ops
+    from sfcvit.training import FusedAdamW, GraphedTrainStep, train_step
+    cfg, batch = MODEL_CASES["hilbert32_1d"]
+    x = formula.image_batch(batch, 3, cfg.img_size, cfg.img_size).cuda()
+    tgt = formula.soft_targets(batch, cfg.num_classes).cuda()
+
+    def fresh():
+        m = build_model(cfg)
+        load_formula(m, cfg)
+        m = m.to("cuda", dtype=torch.bfloat16).train()
+        return m, FusedAdamW(m.parameters(), lr=1e-3, weight_decay=5e-2)
+    try:
+        model_e, opt_e = fresh()
+        opt_e.use_device_state(seed_base=4242)
+        eager = []
+        for _ in range(6):
+            opt_e.advance()
+            eager.append(float(train_step(model_e, x, tgt, opt_e)))
+        model_g, opt_g = fresh()
+        opt_g.use_device_state(seed_base=4242)
+        step = GraphedTrainStep(model_g, x.clone(), tgt.clone(), opt_g, warmup=2)      # 2 eager steps, then capture
+        graphed = [float(step()) for _ in range(4)]
+        assert graphed == eager[2:], (graphed, eager)
+        assert opt_g.step_count == 6 and int(opt_g.dev_state[1]) == 6
+        for (k, a), (_, b) in zip(model_e.state_dict().items(), model_g.state_dict().items()):
+            assert torch.equal(a, b), k
+        assert torch.equal(opt_e.master, opt_g.master) and torch.equal(opt_e.v, opt_g.v)
+        # same weights, same batch, two consecutive seed offsets: different masks -> different training-mode logits
+        with torch.no_grad():
+            opt_g.advance(); a = model_g(x).float()
+            opt_g.advance(); b = model_g(x).float()
+        assert not torch.equal(a, b)
+    finally:
+        ops.STEP_STATE = None
