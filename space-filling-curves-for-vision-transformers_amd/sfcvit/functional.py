@@ -414,3 +414,16 @@ class _SoftCE(Function):
 def soft_target_cross_entropy(logits, targets):
     """-(targets * log_softmax(logits)).sum(-1).mean() with the gradient produced in the same pass."""
     return _SoftCE.apply(_bf(logits), targets)
+
+
+# ----------------------------------------------------------------------------
+# torch.compile (main.py:284 wraps the model in torch.compile(mode="reduce-overhead")).  The blocks above are opaque to
+# Dynamo -- ctypes launches of the C ABI inside autograd.Functions that hand out views of the flat gradient buffer, which
+# a traced custom op may not alias -- so they are declared as such: Dynamo breaks the graph around each block and runs it
+# as written.  What "reduce-overhead" is after (no per-launch host cost) is delivered for the whole training step by
+# sfcvit.training.GraphedTrainStep instead of per compiled region.
+# ----------------------------------------------------------------------------
+for _name in ("patch_embed", "linear", "layer_norm", "gelu", "attention", "mixer_block", "encoder_layer", "predictor_head",
+              "soft_target_cross_entropy"):
+    globals()[_name] = torch.compiler.disable(globals()[_name], recursive=True)
+del _name

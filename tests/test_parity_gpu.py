@@ -492,3 +492,25 @@ def test_graphed_train_step_replays_bit_exactly_and_draws_new_masks():
         assert not torch.equal(a, b)
     finally:
         ops.STEP_STATE = None
+
+
+def test_torch_compile_reduce_overhead_runs_and_matches_eager():
+    """main.py:284: `model = torch.compile(model, mode="reduce-overhead")`.  The HIP blocks are declared opaque to Dynamo
+    (sfcvit/functional.py), so the compiled module must run, give the eager logits bit for bit (eval) and train."""
+    import sfcvit.functional as F
+    cfg, batch = MODEL_CASES["hilbert32_1d"]
+    model = build_model(cfg)
+    load_formula(model, cfg)
+    model = model.to("cuda", dtype=torch.bfloat16).eval()
+    x = formula.image_batch(batch, 3, cfg.img_size, cfg.img_size).cuda()
+    tgt = formula.soft_targets(batch, cfg.num_classes).cuda()
+    with torch.no_grad():
+        want = model(x)
+    compiled = torch.compile(model, mode="reduce-overhead")
+    with torch.no_grad():
+        got = compiled(x)
+    assert torch.equal(got, want)
+    assert all(k.startswith("_orig_mod.") for k in compiled.state_dict())      # the key prefix the reference's checkpoints carry
+    loss = F.soft_target_cross_entropy(compiled(x), tgt)
+    loss.backward()
+    assert all(p.grad is not None for k, p in model.named_parameters() if not k.startswith("mlp_mixer.token_mix"))
