@@ -233,7 +233,16 @@ typedef struct sfcvit_attn_args {
                          row = (b*H + h)*N + q, col = key of the mask function */
     uint32_t dropout_seed;
     const uint32_t *seed_off; /* as in sfcvit_gemm_args */
+    /* backward only, optional: column sums of dqkv over all B * N rows (= the in_proj bias gradient,
+     * torch:nn/functional.py:5822-5833) written to colsum_out ([3 D], fp32 or bf16).  colsum_part = workspace of
+     * sfcvit_attention_colsum_workspace(B, N, H, hd) bytes.  The one-pass kernel (hd = 64, N <= 224) emits the sums
+     * itself; the other paths run sfcvit_colsum over the dqkv they wrote. */
+    float *colsum_part;
+    int64_t colsum_part_bytes;
+    void *colsum_out;
+    int32_t colsum_bf16;
 } sfcvit_attn_args;
+int64_t sfcvit_attention_colsum_workspace(int B, int N, int H, int hd);
 
 int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream);
 int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream);

@@ -336,21 +336,42 @@ extern "C" int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream) {
     return check_launch("attention_fwd");
 }
 
+extern "C" int64_t sfcvit_attention_colsum_workspace(int B, int N, int H, int hd) {
+    if (B <= 0 || N <= 0 || H <= 0 || hd <= 0) return 0;
+    const int64_t fused = int64_t(B) * 3 * H * hd * int64_t(sizeof(float)), generic = sfcvit_colsum_workspace(B * N, 3 * H * hd);
+    return fused > generic ? fused : generic;
+}
+
 extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
     if (int rc = check_args(a, "attention_bwd", true)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int D3 = 3 * a->H * a->hd;
+    if (a->colsum_out && (!a->colsum_part || a->colsum_part_bytes < sfcvit_attention_colsum_workspace(a->B, a->N, a->H, a->hd)))
+        return fail(SFCVIT_EINVAL, "attention_bwd: colsum_out needs colsum_part of sfcvit_attention_colsum_workspace bytes");
+    {   // one pass: dK, dV, dQ, delta and the column sums from a single evaluation of P and dS (hd = 64, N <= 224)
+        const char *env = getenv("SFCVIT_ATTN_BWD_FUSED");       // "0": the two-kernel form (A/B measurements, tests)
+        if (!(env && env[0] == '0')) {
+            sfcvit_attn_args f = *a;
+            if (!a->colsum_out) f.colsum_part = nullptr;
+            if (int rc = attn_seq_bwd_fused(f, s); rc >= 0) {
+                if (rc || !a->colsum_out) return rc;
+                return launch_colsum_reduce(a->colsum_part, a->B, D3, a->colsum_out, a->colsum_bf16, stream);
+            }
+        }
+    }
+    const int rc_rest = [&]() -> int {
     const int64_t groups = int64_t(a->B) * a->N * a->H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(unsigned((groups * 8 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s,
                        static_cast<const uint16_t *>(a->dout), static_cast<const uint16_t *>(a->out), a->delta, a->B, a->N, a->H, a->hd);
     if (int rc = check_launch("attention_bwd delta")) return rc;
     if (int rc = attn_wide_bwd(*a, s); rc >= 0) return rc;
-    const char *env = getenv("SFCVIT_ATTN_BWD_FUSED");       // "0": the two-kernel form (A/B measurements, tests)
-    if (!(env && env[0] == '0'))
-        if (int rc = attn_seq_bwd_fused(*a, s); rc >= 0) return rc;
     if (int rc = attn_seq_bwd(*a, s); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
     hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(THREADS), 0, s, *a);
     if (int rc = check_launch("attention_bwd kv")) return rc;
     hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(THREADS), 0, s, *a);
     return check_launch("attention_bwd q");
+    }();
+    if (rc_rest || !a->colsum_out) return rc_rest;
+    return sfcvit_colsum(a->dqkv, a->B * a->N, D3, D3, a->colsum_out, a->colsum_bf16, a->colsum_part, a->colsum_part_bytes, stream);
 }

@@ -16,6 +16,11 @@
 //     32 head columns each, and store it.  One workgroup barrier per chunk orders writer and reader; the two halves of
 //     the exchange image alternate.  Every dQ tile is summed by one wave in a fixed key order: results are bit-identical
 //     from run to run (no atomics).
+//   * delta = rowsum(dO . O) is worked out here as well, from the staged dO image and one 16-byte load of O per thread
+//     (the two-kernel form runs a separate pass over dO and O for it), and -- when the caller asks -- the column sums
+//     of dQ, dK, dV over the sequence (= this (batch, head)'s contribution to the in_proj bias gradient,
+//     torch:nn/functional.py:5822-5833) leave the kernel as 192 floats instead of being re-read from the 231 MB dqkv
+//     tensor by a column-sum pass.
 //   * rows >= N: the DMA fills them with copies of row N - 1 (finite); padded queries get lse = +inf (P = dS = 0), padded
 //     keys get dS = 0 before the exchange and their dK / dV rows are not stored; exchange rows of keys >= 16 nf are
 //     zeroed once.
@@ -64,26 +69,35 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     char *qimg = smem, *doimg = smem + npad * 128, *kimg = smem + 2 * npad * 128, *dsb = smem + 3 * npad * 128;
     float *lse_s = reinterpret_cast<float *>(dsb + 2 * npad * 64), *del_s = lse_s + npad;
     uint32_t *rkey_s = reinterpret_cast<uint32_t *>(del_s + npad);   // dropout row key of every query
+    float *qcs = reinterpret_cast<float *>(rkey_s + npad);           // [64] column sums of dQ (dQ waves)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y, h = blockIdx.x, N = a.N, D = a.H * HD, ld = 3 * D;
     const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
     const uint16_t *qp = base, *kp = base + D, *vp = base + 2 * D;
     const uint16_t *dop = static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD;
-    const float *lse = a.lse + (size_t(b) * a.H + h) * N, *del = a.delta + (size_t(b) * a.H + h) * N;
+    const float *lse = a.lse + (size_t(b) * a.H + h) * N;
     const int nf = NFC ? NFC : (N + 15) >> 4, nc = NFC ? ((NFC + 1) >> 1) : npad >> 5;
     const bool is_key = wave < nf, is_dq = wave >= FWAVES - 2;
     bf16x8 kf[2], vf[2];                              // this wave's 16 keys: V from HBM here, K from the staged image below
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) vf[kk] = global_frag(vp, ld, 16 * wave, is_key ? N : 0, kk, lane);
+    // O, for delta: the 16-byte piece that pairs with this thread's piece(s) of the dO image (same row, same swizzled chunk)
+    u32x4 opiece[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int p = tid + FT * i, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+        opiece[i] = u32x4{0u, 0u, 0u, 0u};
+        if (row < N) opiece[i] = *reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(a.out) + (size_t(b) * N + row) * D + h * HD + c * 8);
+    }
     dma_rows(qimg, qp, ld, N, npad, tid);
     dma_rows(doimg, dop, D, N, npad, tid);
     dma_rows(kimg, kp, ld, N, npad, tid);
     const uint32_t dth = drop_thresh(a.dropout_p);
     for (int i = tid; i < npad; i += FT) {
         lse_s[i] = i < N ? lse[i] * 1.4426950408889634f : INFINITY;   // padded queries: p = exp2(-inf) = 0
-        del_s[i] = i < N ? del[i] : 0.f;
         rkey_s[i] = drop_row_key(eff_seed(a.dropout_seed, a.seed_off), (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(i));
     }
+    if (tid < 64) qcs[tid] = 0.f;
     {   // exchange rows no key wave writes (keys 16 nf .. npad - 1), both halves of the double buffer
         const int nz = (npad - 16 * nf) * 4;         // 16-byte pieces per half
         for (int i = tid; i < 2 * nz; i += FT) {
@@ -92,16 +106,37 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         }
     }
     __syncthreads();                                  // LDS-DMA pending: hipcc drains vmcnt(0) here
+    // delta[q] = sum_c dO[q][c] O[q][c]: 8 products per thread and piece, summed over the 8 lanes that share a row
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int p = tid + FT * i, row = p >> 3;
+        float part = 0.f;
+        if (p < npad * 8) {
+            const u32x4 dpiece = *reinterpret_cast<const u32x4 *>(doimg + p * 16);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                part += __uint_as_float(dpiece[j] << 16) * __uint_as_float(opiece[i][j] << 16);
+                part += __uint_as_float(dpiece[j] & 0xFFFF0000u) * __uint_as_float(opiece[i][j] & 0xFFFF0000u);
+            }
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if ((tid & 7) == 0 && p < npad * 8) del_s[row] = part;          // rows >= N: O piece = 0 -> 0
+    }
+    __syncthreads();
 
     const float scale = a.scale, c2 = a.scale * 1.4426950408889634f;
-    const LaneOff lo = lane_offsets(lane);
+    // lane offsets of the fragment reads: the XOR swizzle commutes with the fragment index, so ONE register per kind
+    // (k_off ^ (kk << 6), t_off ^ (hf << 5)) instead of the six of LaneOff -- the register file is full
+    const int k_off = lane_offsets(lane).k[0], t_off = lane_offsets(lane).t[0];
     const float dsc = 1.f / (1.f - a.dropout_p);
     uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
     const int g = lane >> 4, li = lane & 15;
     const int key = 16 * wave + li;                   // key waves: the key this lane's accumulator columns belong to
     if (is_key) {                                     // rows >= N of the image copy row N - 1: those keys are masked below
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) kf[kk] = kc_frag_at(kimg, 16 * wave, lo.k[kk]);
+        for (int kk = 0; kk < 2; kk++) kf[kk] = kc_frag_at(kimg, 16 * wave, (k_off ^ (kk << 6)));
     } else {
         kf[0] = kf[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
@@ -121,8 +156,8 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(qimg, 16 * qf, lo.k[kk]), kf[kk], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(doimg, 16 * qf, lo.k[kk]), vf[kk], dp, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(qimg, 16 * qf, (k_off ^ (kk << 6))), kf[kk], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_frag_at(doimg, 16 * qf, (k_off ^ (kk << 6))), vf[kk], dp, 0, 0, 0);
                 }
                 const int ql0 = 16 * qf + 4 * g;                     // this lane's 4 queries: one 16-B LDS read each
                 const f32x4 lse4 = *reinterpret_cast<const f32x4 *>(lse_s + ql0);    // lse * log2(e)
@@ -154,8 +189,8 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
             }
 #pragma unroll
             for (int hf = 0; hf < 4; hf++) {
-                dv[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_at(doimg, 32 * c, lo.t[hf]), pf, dv[hf], 0, 0, 0);
-                dk[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_at(qimg, 32 * c, lo.t[hf]), dsf, dk[hf], 0, 0, 0);
+                dv[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_at(doimg, 32 * c, (t_off ^ (hf << 5))), pf, dv[hf], 0, 0, 0);
+                dk[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_at(qimg, 32 * c, (t_off ^ (hf << 5))), dsf, dk[hf], 0, 0, 0);
             }
         } else if (is_dq && c >= 1) {
             const char *slot = dsb + ((c - 1) & 1) * npad * 64;
@@ -186,6 +221,17 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
                 }
             }
             mfma_fence();
+            if (a.colsum_part) {
+                // column sums of this chunk's dQ tiles, accumulated in this wave's 32 LDS words (one writer per word, chunk
+                // after chunk: a fixed order; registers for running sums are not to be had).  Padded queries have dS = 0.
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float sq = row16_sum(acc[hh][0][r] + acc[hh][1][r]);
+                        if (li == 0) qcs[32 * dqw + 16 * hh + 4 * g + r] += sq;
+                    }
+            }
             // acc[hh][qf][r] = dQ[query 32 (c-1) + 16 qf + li][head column 32 dqw + 16 hh + 4 g + r]
 #pragma unroll
             for (int qf = 0; qf < 2; qf++) {
@@ -207,11 +253,40 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         store_rows(dbase + D, ld, key, key < N, dk, scale, lane);
         store_rows(dbase + 2 * D, ld, key, key < N, dv, 1.f, lane);
     }
+    if (a.colsum_part) {
+        // column sums of this (batch, head)'s dQ | dK | dV block: lanes of a 16-lane row hold the 16 rows of a column
+        // (DPP reduction), the 13 key waves / 2 dQ waves meet in LDS (the exchange image is free now) and are summed in
+        // a fixed order: bit-reproducible.  Layout of the partials: [batch][q | k | v thirds of 3 D], summed over
+        // the batch afterwards (launch_colsum_reduce).
+        float *cs = reinterpret_cast<float *>(dsb);              // [FWAVES][128]
+        if (is_key) {
+#pragma unroll
+            for (int hf = 0; hf < 4; hf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float sk = row16_sum(key < N ? dk[hf][r] : 0.f), sv = row16_sum(key < N ? dv[hf][r] : 0.f);
+                    if (li == 0) {
+                        cs[wave * 128 + 16 * hf + 4 * g + r] = sk * scale;
+                        cs[wave * 128 + 64 + 16 * hf + 4 * g + r] = sv;
+                    }
+                }
+        }
+        __syncthreads();
+        if (tid < 192) {
+            const int third = tid >> 6, c = tid & 63;
+            float s = 0.f;
+            if (third == 0) s = qcs[c] * scale;
+            else
+                for (int w = 0; w < nf; w++) s += cs[w * 128 + (third - 1) * 64 + c];
+            a.colsum_part[size_t(b) * 3 * D + third * D + h * HD + c] = s;
+        }
+    }
 }
 
 constexpr int FUSED_MAX_N = 32 * FMAXC;
 constexpr int FUSED_ROW_BYTES = 3 * 128 + 2 * 64 + 3 * 4;    // LDS bytes per padded sequence row
-constexpr int FUSED_MAX_LDS = FUSED_MAX_N * FUSED_ROW_BYTES;
+constexpr int FUSED_EXTRA = 256;                             // + 64 column sums of dQ
+constexpr int FUSED_MAX_LDS = FUSED_MAX_N * FUSED_ROW_BYTES + FUSED_EXTRA;
 
 }  // namespace
 
@@ -229,7 +304,7 @@ int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s) {
         done = true;
     }
     const int npad = (a.N + 31) / 32 * 32;
-    const size_t lds = size_t(npad) * FUSED_ROW_BYTES;
+    const size_t lds = size_t(npad) * FUSED_ROW_BYTES + FUSED_EXTRA;
     const bool nf13 = (a.N + 15) / 16 == 13, drop = a.dropout_p > 0.f;
     const dim3 grid(a.H, a.B), block(FT);
     if (nf13 && drop) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<13, true>), grid, block, lds, s, a, npad);

@@ -83,15 +83,6 @@ struct Cursor {            // the k-tile being staged for one operand: index in 
 // `side` = the 16 bf16 of this row segment of the residual (RES) or of aux_in (DACT), loaded by the caller for ALL
 // rows before the first use: hipcc puts one `s_waitcnt vmcnt(0)` in front of the first use of an ordinary load while
 // LDS-DMA is in flight, so loading row by row paid one memory latency per row.
-// Sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane of the row.
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-    return v;
-}
-
 // Where a lane's packed output goes: the wave's [16 rows][64 columns] of one fragment row pass through a wave-private
 // LDS patch ([16][128 B], 16-byte chunk index XOR-ed with row & 7) so that the global stores are row-contiguous.
 struct StoreMap {

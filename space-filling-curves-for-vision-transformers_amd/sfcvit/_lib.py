@@ -38,7 +38,8 @@ class AttnArgs(ctypes.Structure):
     _fields_ = [("qkv", c_void_p), ("out", c_void_p), ("lse", c_void_p), ("dout", c_void_p),
                 ("dqkv", c_void_p), ("delta", c_void_p),
                 ("B", c_int32), ("N", c_int32), ("H", c_int32), ("hd", c_int32), ("scale", c_float),
-                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("seed_off", c_void_p)]
+                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("seed_off", c_void_p),
+                ("colsum_part", c_void_p), ("colsum_part_bytes", c_int64), ("colsum_out", c_void_p), ("colsum_bf16", c_int32)]
 
 
 class AdamWArgs(ctypes.Structure):
@@ -82,6 +83,7 @@ SIGNATURES = {
     "sfcvit_dropout_mask": (c_int, [c_void_p, c_int64, c_int, c_float, ctypes.c_uint32, c_void_p]),
     "sfcvit_attention_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "sfcvit_attention_bwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
+    "sfcvit_attention_colsum_workspace": (c_int64, [c_int, c_int, c_int, c_int]),
     "sfcvit_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "sfcvit_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sfcvit_soft_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

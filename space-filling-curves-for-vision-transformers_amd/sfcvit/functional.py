@@ -323,8 +323,14 @@ class _EncoderLayer(Function):
         o2 = o.view(B * N, D)
         dwo = wg(da, o2, out_w)
         do = ops.gemm_dx(da, out_w)
-        dqkv = ops.attention_bwd(qkv.view(B, N, 3 * D), o, lse, do.view(B, N, D), ctx.n_heads, p, sa).view(B * N, 3 * D)
-        dwi, dbi = wg(dqkv, x2, in_w), _bgrad(dqkv, in_b)
+        # the in_proj bias gradient (column sums of dqkv) comes out of the attention backward itself
+        bi_slot = _slot(in_b)
+        dqkv, dbi = ops.attention_bwd(qkv.view(B, N, 3 * D), o, lse, do.view(B, N, D), ctx.n_heads, p, sa,
+                                      colsum=bi_slot if bi_slot is not None else True)
+        dqkv = dqkv.view(B * N, 3 * D)
+        if bi_slot is None:
+            dbi = dbi.to(_BF16)
+        dwi = wg(dqkv, x2, in_w)
         dx = ops.gemm_dx(dqkv, in_w, residual=ds1)
         if ss:
             ss.join(dw2, dw1, dwo, dwi)

@@ -346,7 +346,9 @@ def attention_fwd(qkv, n_heads, dropout_p=0.0, dropout_seed=0):
     return out, lse
 
 
-def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0):
+def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0, colsum=None):
+    """-> dqkv [, column sums of dqkv over all B * N rows = the in_proj bias gradient: colsum=True -> fp32 [3D] (new
+    tensor), or a bf16 [3D] tensor to write into (e.g. a slot of the flat gradient buffer)]."""
     _need(dout, _BF16, "attention dout", 3)
     B, N, D3 = qkv.shape
     D, hd = _attn_dims(D3, n_heads)
@@ -359,9 +361,18 @@ def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0):
     a.dropout_p, a.dropout_seed = dropout_p, dropout_seed
     if dropout_p > 0.0 and STEP_STATE is not None:
         a.seed_off = STEP_STATE.data_ptr()
+    cs = None
+    if colsum is not None and colsum is not False:
+        cs = torch.empty(D3, device=qkv.device, dtype=torch.float32) if colsum is True else colsum
+        if cs.numel() != D3 or not cs.is_contiguous() or cs.dtype not in (torch.float32, _BF16):
+            raise ValueError("attention_bwd colsum: contiguous fp32 or bf16 [3D] expected")
+        nbytes = lib.sfcvit_attention_colsum_workspace(B, N, n_heads, hd)
+        ws = torch.empty(nbytes, device=qkv.device, dtype=torch.uint8)
+        a.colsum_part, a.colsum_part_bytes = ws.data_ptr(), nbytes
+        a.colsum_out, a.colsum_bf16 = cs.data_ptr(), int(cs.dtype == _BF16)
     check(_launch("attn_bwd", 10.0 * B * n_heads * N * N * hd,
                   lambda: lib.sfcvit_attention_bwd(ctypes.byref(a), _stream())), "sfcvit_attention_bwd")
-    return dqkv
+    return dqkv if cs is None else (dqkv, cs)
 
 
 # ----------------------------------------------------------------------------

@@ -553,3 +553,23 @@ def test_patch_embed_tiled_vs_generic_and_reference(ops, curve, img, D, B, xdt):
     ref = tok @ w.float().t() + b.float()
     close(tiled, ref, rel=1 / 100, abs_scale=1 / 100)
     assert torch.equal(tiled, ops.patch_embed_fwd(x, pix, w, b, desc))
+
+
+@pytest.mark.parametrize("B,N,H,p", [(3, 196, 2, 0.1), (2, 100, 3, 0.0), (2, 300, 1, 0.0)])
+def test_attention_bwd_column_sums(ops, B, N, H, p):
+    """The in_proj bias gradient as a by-product of the attention backward: 192 sums per (batch, head) out of the one-pass
+    kernel (N <= 224) or a column-sum pass over dqkv (longer sequences) -- against the column sums of the dqkv the same
+    call returned (fp32 sums of the bf16-rounded values differ from the kernel's sums of the unrounded ones by rounding)."""
+    g = torch.Generator(device="cuda").manual_seed(13)
+    D = H * 64
+    qkv = bf(torch.randn(B, N, 3 * D, device="cuda", generator=g))
+    dout = bf(torch.randn(B, N, D, device="cuda", generator=g))
+    out, lse = ops.attention_fwd(qkv, H, p, 99)
+    plain = ops.attention_bwd(qkv, out, lse, dout, H, p, 99)
+    dqkv, cs = ops.attention_bwd(qkv, out, lse, dout, H, p, 99, colsum=True)
+    assert torch.equal(dqkv, plain)
+    ref = dqkv.float().sum((0, 1))
+    close(cs, ref, rel=1 / 100, abs_scale=1 / 100)
+    slot = torch.zeros(3 * D, device="cuda", dtype=torch.bfloat16)
+    _, cs2 = ops.attention_bwd(qkv, out, lse, dout, H, p, 99, colsum=slot)
+    assert cs2 is slot and torch.equal(slot, cs.to(torch.bfloat16))
