@@ -104,7 +104,7 @@ typedef struct sfcvit_patch_embed_args {
 
 /* HOST: analyse a pixel table (host copy of sfcvit_pixel_table's output): > 0 = number of int32 written to `desc`
  * (every token is a 16 x 16 pixel tile or a strip of 256 consecutive pixels), 0 = not tileable, < 0 = error.
- * Capacity 16 + 2 N + 8 * 256 always suffices. */
+ * Capacity 16 + 2 N + 2 * 8 * 256 always suffices. */
 int sfcvit_tile_descriptors(const int32_t *pix, int N, int P, int img_w, int32_t *desc, int capacity);
 
 /* HOST: workspace bytes for fwd (bwd = 0) / bwd (bwd = 1). */

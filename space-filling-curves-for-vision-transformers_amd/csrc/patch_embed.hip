@@ -233,6 +233,8 @@ Geo make_geo(const sfcvit_patch_embed_args *a) {
 
 namespace sfcvit {
 int pe2_fwd(const sfcvit_patch_embed_args &a, hipStream_t s);      // patch_embed_tiled.hip; -1 = not eligible
+int pe2_bwd(const sfcvit_patch_embed_args &a, hipStream_t s);
+int64_t pe2_bwd_workspace(int B, int C, int N, int D);
 }
 
 using namespace sfcvit;
@@ -243,7 +245,9 @@ extern "C" int64_t sfcvit_patch_embed_workspace(int B, int C, int N, int P, int 
     if (!bwd) return ((int64_t(D) * K * 2 * 8 + 15) / 16) * 16;      // up to 8 class-permuted copies of W (tiled forward)
     const int64_t slabs = int64_t(bwd_splits(B * N, D, int(K))) * D * K * int64_t(sizeof(float));
     const int64_t bias_ws = sfcvit_colsum_workspace(B * N, D);   // dbias reuses the buffer after the slabs are reduced
-    return slabs > bias_ws ? slabs : bias_ws;
+    const int64_t tiled = (P == 256 && D % 256 == 0) ? pe2_bwd_workspace(B, C, N, D) : 0;
+    const int64_t m = slabs > bias_ws ? slabs : bias_ws;
+    return m > tiled ? m : tiled;
 }
 
 extern "C" int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *stream) {
@@ -278,6 +282,10 @@ extern "C" int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *st
     if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace))
         return fail(SFCVIT_EINVAL, "patch_embed_bwd: workspace of %lld bytes needed", (long long)need);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = pe2_bwd(*a, s); rc >= 0) {                          // tiles / strips: the coalesced kernel
+        if (rc || !a->dbias) return rc;
+        return sfcvit_colsum(a->y, a->B * a->N, a->D, a->D, a->dbias, 0, a->workspace, a->workspace_bytes, stream);
+    }
     const Geo g = make_geo(a);
     const int splits = bwd_splits(g.M, a->D, g.Kp);
     const int ktiles = (g.M + BK - 1) / BK;

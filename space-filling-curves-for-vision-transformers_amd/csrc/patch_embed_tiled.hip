@@ -190,6 +190,156 @@ __global__ __launch_bounds__(PT) void pe2_fwd_kernel(const void *__restrict__ x,
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Backward: dW'[cls][d][c*256 + j] = sum over the class's token rows of dY[row][d] * tile_pixel[row][c][j], then
+// dW[d][k*C + c] = sum over classes of dW'[cls][d][c*256 + inverse_perm_cls(k)].  One workgroup = one 256 (d) x 256
+// (the 256 pixels of ONE channel) output tile over one range of the class's rows; per step of 64 rows every thread loads
+// two 16-pixel row segments of its row's tile (whole segments, 16-byte vectors) and 64 bytes of its dY row, both go
+// into k-major LDS images (device_common.h "st" layout) and are read as MFMA fragments by ds_read_b64_tr_b16 -- the
+// loop of the weight-gradient GEMM (gemm8p.hip) with the gather as its B loader.  fp32 partial tiles go to slabs
+// (deterministic fixed-order reduction, no atomics).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int BW_ROWS = 64, BW_IMG = BW_ROWS * 256;          // rows per step; one [64][128] st image
+
+template <bool XBF16>
+__global__ __launch_bounds__(PT) void pe2_bwd_kernel(const void *__restrict__ x, const int32_t *__restrict__ desc,
+                                                     const uint16_t *__restrict__ dy, float *__restrict__ slabs,
+                                                     int B, int C, int HW, int D, int KR) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x [dY half 0 | dY half 1 | X half 0 | X half 1]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3;
+    const int ncls = desc[1], sstep = desc[3], N = desc[4], K = C * 256;
+    const int32_t *toks = desc + DESC_HDR, *origin = desc + DESC_HDR + N;
+    const int NDT = D / 256, tiles = NDT * C;
+    // unit -> (class, row range z, d tile, channel)
+    int u = blockIdx.x, cls = -1, cnt = 0, tok0 = 0, z = 0, ubase = 0;
+    for (int c = 0; c < ncls; c++) {
+        const int t0 = desc[6 + c], n_c = desc[6 + c + 1] - t0, nz = (n_c * B + KR - 1) / KR;
+        if (u < nz * tiles) { cls = c; cnt = n_c; tok0 = t0; z = u / tiles; u -= z * tiles; break; }
+        u -= nz * tiles;
+        ubase += nz;
+    }
+    if (cls < 0) return;
+    const int dt = u / C, ch = u % C;
+    const int row_beg = z * KR, row_end = min(row_beg + KR, cnt * B), nsteps = (row_end - row_beg + BW_ROWS - 1) / BW_ROWS;
+
+    const int srow = tid >> 3, sub = tid & 7;                        // staging: one row, 2 segments + 32 d per thread
+    constexpr int NX = XBF16 ? 4 : 8;
+    u32x4 xr[NX], yr[4];
+    auto load_stage = [&](int st) __attribute__((always_inline)) {
+        const int ml = row_beg + st * BW_ROWS + srow;
+        const bool valid = ml < row_end;
+        const int mc = valid ? ml : row_end - 1;
+        const int n = toks[tok0 + mc / B], b = mc % B;
+        const long long xoff = ((long long)(b) * C + ch) * HW + origin[n] + (2 * sub) * sstep;
+        if (XBF16) {
+            const uint16_t *px = static_cast<const uint16_t *>(x) + xoff;
+#pragma unroll
+            for (int sgi = 0; sgi < 2; sgi++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) xr[2 * sgi + i] = *reinterpret_cast<const u32x4 *>(px + sgi * sstep + 8 * i);
+        } else {
+            const float *px = static_cast<const float *>(x) + xoff;
+#pragma unroll
+            for (int sgi = 0; sgi < 2; sgi++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) xr[4 * sgi + i] = *reinterpret_cast<const u32x4 *>(px + sgi * sstep + 4 * i);
+        }
+        const uint16_t *py = dy + (size_t(b) * N + n) * D + dt * 256 + 32 * sub;
+#pragma unroll
+        for (int i = 0; i < 4; i++) yr[i] = valid ? *reinterpret_cast<const u32x4 *>(py + 8 * i) : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto write_stage = [&](int buf) __attribute__((always_inline)) {
+        char *base = smem + buf * 4 * BW_IMG;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                                // dY: d columns 32 sub + 8 i of this row
+            const int col = 32 * sub + 8 * i;
+            *reinterpret_cast<u32x4 *>(base + (col >> 7) * BW_IMG + st_off(srow, col & 127)) = yr[i];
+        }
+#pragma unroll
+        for (int sgi = 0; sgi < 2; sgi++) {                          // X: segment 2 sub + sgi = pixels 16 seg .. +15 of the channel
+            const int seg = 2 * sub + sgi, col = (seg & 7) * 16;
+            char *img = base + (2 + (seg >> 3)) * BW_IMG;
+            u32x4 lo, hi;
+            if (XBF16) {
+                lo = xr[2 * sgi]; hi = xr[2 * sgi + 1];
+            } else {
+                const float *f = reinterpret_cast<const float *>(xr) + 16 * sgi;
+                lo = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+                hi = u32x4{pack2bf(f[8], f[9]), pack2bf(f[10], f[11]), pack2bf(f[12], f[13]), pack2bf(f[14], f[15])};
+            }
+            *reinterpret_cast<u32x4 *>(img + st_off(srow, col)) = lo;
+            *reinterpret_cast<u32x4 *>(img + st_off(srow, col + 8)) = hi;
+        }
+    };
+
+    f32x4 acc[8][4];                                                 // wave tile: 128 d (wr) x 64 pixels (wc)
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_stage(0);
+    write_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; st++) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps) load_stage(st + 1);
+        const char *base = smem + cur * 4 * BW_IMG;
+        const char *yimg = base + wr * BW_IMG, *ximg = base + (2 + (wc >> 1)) * BW_IMG;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            bf16x8 fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) fb[j] = st_frag(ximg, (wc & 1) * 64 + 16 * j, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const bf16x8 fa = st_frag(yimg, 16 * i, kk, lane);
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nsteps) write_stage(cur ^ 1);
+        __syncthreads();
+    }
+    mfma_fence();
+    // acc[i][j][r] = dW'[d = dt*256 + 128 wr + 16 i + 4 (lane >> 4) + r][pixel 64 wc + 16 j + (lane & 15)] of channel ch
+    float *slab = slabs + (size_t(ubase + z) * D + dt * 256 + 128 * wr + 4 * (lane >> 4)) * K + ch * 256 + 64 * wc + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) slab[size_t(16 * i + r) * K + 16 * j] = acc[i][j][r];
+}
+
+// dW[d][k*C + c] = sum over classes and their row ranges of slab[u][d][c*256 + inverse_perm_cls(k)]
+__global__ __launch_bounds__(256) void pe2_bwd_reduce(const float *__restrict__ slabs, const int32_t *__restrict__ desc, float *__restrict__ dw,
+                                                      int B, int C, int D, int KR) {
+    const int K = C * 256, ncls = desc[1], N = desc[4];
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= int64_t(D) * K) return;
+    const int d = int(i / K), f = int(i % K), k = f / C, c = f % C;
+    const int32_t *inv = desc + DESC_HDR + 2 * N + ncls * 256;
+    float s = 0.f;
+    int ubase = 0;
+    for (int cl = 0; cl < ncls; cl++) {
+        const int n_c = desc[6 + cl + 1] - desc[6 + cl], nz = (n_c * B + KR - 1) / KR;
+        const int j = inv[cl * 256 + k];
+        for (int z = 0; z < nz; z++) s += slabs[(size_t(ubase + z) * D + d) * K + c * 256 + j];
+        ubase += nz;
+    }
+    dw[i] = s;
+}
+
+constexpr int PE2_BWD_LDS = 2 * 4 * BW_IMG;
+
+int pe2_bwd_row_range(int M) {                   // rows per unit: ~256 units for D = 768, C = 3
+    int kr = (9 * M + 255) / 256;
+    kr = (kr + BW_ROWS - 1) / BW_ROWS * BW_ROWS;
+    return kr < 256 ? 256 : kr;
+}
+
 constexpr int PE2_LDS = 2 * A_BYTES + 2 * B_BYTES + TM * int(sizeof(RowInfo));
 
 }  // namespace
@@ -226,6 +376,39 @@ int pe2_fwd(const sfcvit_patch_embed_args &a, hipStream_t s) {
     return check_launch("patch_embed_fwd (tiled)");
 }
 
+// Tiled backward: -1 = not eligible.  Workspace: fp32 slabs, one [D][C*256] per (class, row range).
+int64_t pe2_bwd_workspace(int B, int C, int N, int D) {
+    const int M = B * N, KR = pe2_bwd_row_range(M);
+    return (int64_t(M / KR) + 2 * MAXCLS) * D * C * 256 * int64_t(sizeof(float));
+}
+
+int pe2_bwd(const sfcvit_patch_embed_args &a, hipStream_t s) {
+    if (!a.desc || a.P != 256 || a.D % 256 || a.desc_ncls <= 0 || a.desc_ncls > MAXCLS) return -1;
+    if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.HW & 7)) return -1;
+    const int KR = pe2_bwd_row_range(a.B * a.N);
+    int nz = 0;
+    for (int c = 0; c < a.desc_ncls; c++) nz += int((int64_t(a.desc_cnt[c]) * a.B + KR - 1) / KR);
+    const int64_t need = int64_t(nz) * a.D * a.C * 256 * int64_t(sizeof(float));
+    if (!a.workspace || a.workspace_bytes < need) return -1;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pe2_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PE2_BWD_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&pe2_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PE2_BWD_LDS) != hipSuccess)
+            return check_launch("patch_embed_bwd (tiled) attribute");
+        attr = true;
+    }
+    float *slabs = static_cast<float *>(a.workspace);
+    dim3 grid(unsigned(nz) * unsigned((a.D / 256) * a.C)), block(PT);
+    if (a.x_is_bf16)
+        hipLaunchKernelGGL(pe2_bwd_kernel<true>, grid, block, PE2_BWD_LDS, s, a.x, a.desc, static_cast<const uint16_t *>(a.y), slabs, a.B, a.C, a.HW, a.D, KR);
+    else
+        hipLaunchKernelGGL(pe2_bwd_kernel<false>, grid, block, PE2_BWD_LDS, s, a.x, a.desc, static_cast<const uint16_t *>(a.y), slabs, a.B, a.C, a.HW, a.D, KR);
+    if (int rc = check_launch("patch_embed_bwd (tiled)")) return rc;
+    const int64_t nw = int64_t(a.D) * a.C * 256;
+    hipLaunchKernelGGL(pe2_bwd_reduce, dim3(unsigned((nw + 255) / 256)), dim3(256), 0, s, slabs, a.desc, static_cast<float *>(a.dw), a.B, a.C, a.D, KR);
+    return check_launch("patch_embed_bwd (tiled) reduce");
+}
+
 }  // namespace sfcvit
 
 using namespace sfcvit;
@@ -236,7 +419,7 @@ using namespace sfcvit;
 // (use the generic path); < 0 = error.  desc: [0] mode (1 tile, 2 strip) [1] classes [2] k-tile step [3] segment step
 // [4] N [5] 256 [6 .. 6+classes] first token (in `toks`) of each class, then N; [16 .. 16+N) token ids grouped by
 // class; [16+N .. 16+2N) pixel offset of each token's origin; then classes x 256 curve positions of the tile's pixels
-// in raster order.
+// in raster order, then classes x 256 inverse tables (curve position -> raster pixel).
 extern "C" int sfcvit_tile_descriptors(const int32_t *pix, int N, int P, int img_w, int32_t *desc, int capacity) {
     if (!pix || !desc || N <= 0 || img_w <= 0) return fail(SFCVIT_EINVAL, "tile_descriptors: bad argument");
     if (P != 256 || (img_w & 7)) return 0;
@@ -279,7 +462,7 @@ extern "C" int sfcvit_tile_descriptors(const int32_t *pix, int N, int P, int img
         }
     }
     const int ncls = int(perms.size());
-    const int total = DESC_HDR + 2 * N + ncls * 256;
+    const int total = DESC_HDR + 2 * N + 2 * ncls * 256;
     if (capacity < total) return fail(SFCVIT_EINVAL, "tile_descriptors: capacity %d < %d", capacity, total);
     std::memset(desc, 0, sizeof(int32_t) * DESC_HDR);
     desc[0] = mode; desc[1] = ncls;
@@ -295,6 +478,9 @@ extern "C" int sfcvit_tile_descriptors(const int32_t *pix, int N, int P, int img
     desc[6 + ncls] = t;
     for (int n = 0; n < N; n++) desc[DESC_HDR + N + n] = origin[n];
     for (int c = 0; c < ncls; c++)
-        for (int j = 0; j < 256; j++) desc[DESC_HDR + 2 * N + c * 256 + j] = perms[c][j];
+        for (int j = 0; j < 256; j++) {
+            desc[DESC_HDR + 2 * N + c * 256 + j] = perms[c][j];                              // raster pixel j -> curve position
+            desc[DESC_HDR + 2 * N + (ncls + c) * 256 + perms[c][j]] = j;                     // curve position -> raster pixel
+        }
     return total;
 }

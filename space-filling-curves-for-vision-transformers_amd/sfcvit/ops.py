@@ -394,7 +394,7 @@ def tile_descriptor(pix_host, img_w, device):
     import numpy as np
     N, P = pix_host.shape
     pix_host = np.ascontiguousarray(pix_host, dtype=np.int32)
-    cap = 16 + 2 * N + 8 * 256
+    cap = 16 + 2 * N + 2 * 8 * 256
     out = np.zeros(cap, dtype=np.int32)
     n = lib.sfcvit_tile_descriptors(ctypes.c_void_p(pix_host.ctypes.data), N, P, int(img_w), ctypes.c_void_p(out.ctypes.data), cap)
     if n < 0:

@@ -298,16 +298,19 @@ def test_tile_descriptors_reconstruct_the_pixel_table(curve, img, expect):
     flat = np.arange(img * img, dtype=np.int32) if curve == "raster" else curve_table({"hilbert": hilbert_curve, "z": z_curve}[curve], img)
     pix = _pixel_table(flat, img, 1, 256)
     N = pix.shape[0]
-    cap = 16 + 2 * N + 8 * 256
+    cap = 16 + 2 * N + 2 * 8 * 256
     desc = np.zeros(cap, dtype=np.int32)
     n = lib.sfcvit_tile_descriptors(ctypes.c_void_p(pix.ctypes.data), N, 256, img, ctypes.c_void_p(desc.ctypes.data), cap)
-    assert n == 16 + 2 * N + expect[1] * 256
+    assert n == 16 + 2 * N + 2 * expect[1] * 256
     mode, ncls = int(desc[0]), int(desc[1])
     assert (mode, ncls) == expect and desc[4] == N
     starts = desc[6:6 + ncls + 1]
     assert starts[0] == 0 and starts[-1] == N
     toks, origin = desc[16:16 + N], desc[16 + N:16 + 2 * N]
-    perm = desc[16 + 2 * N:n].reshape(ncls, 256)
+    perm = desc[16 + 2 * N:16 + 2 * N + ncls * 256].reshape(ncls, 256)
+    inv = desc[16 + 2 * N + ncls * 256:n].reshape(ncls, 256)
+    for c in range(ncls):
+        assert np.array_equal(inv[c][perm[c]], np.arange(256))
     assert sorted(toks.tolist()) == list(range(N))
     j = np.arange(256)
     local = (j // 16) * img + j % 16 if mode == 1 else j
@@ -322,7 +325,7 @@ def test_tile_descriptors_decline_other_tokenizers():
     from sfcvit._lib import lib
     from sfcvit.tokenizers.embeddings import _pixel_table
     from sfcvit.curves import curve_table, hilbert_curve
-    desc = np.zeros(16 + 2 * 4096 + 2048, dtype=np.int32)
+    desc = np.zeros(16 + 2 * 4096 + 4096, dtype=np.int32)
     # 64 pixels per token: not 256
     pix = _pixel_table(curve_table(hilbert_curve, 32), 32, 1, 64)
     assert lib.sfcvit_tile_descriptors(ctypes.c_void_p(pix.ctypes.data), pix.shape[0], 64, 32, ctypes.c_void_p(desc.ctypes.data), desc.size) == 0

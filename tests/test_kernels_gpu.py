@@ -573,3 +573,30 @@ def test_attention_bwd_column_sums(ops, B, N, H, p):
     slot = torch.zeros(3 * D, device="cuda", dtype=torch.bfloat16)
     _, cs2 = ops.attention_bwd(qkv, out, lse, dout, H, p, 99, colsum=slot)
     assert cs2 is slot and torch.equal(slot, cs.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("curve,img,D,B,xdt", [("hilbert", 224, 768, 3, torch.float32), ("hilbert", 224, 256, 70, torch.bfloat16),
+                                               ("z", 384, 1024, 2, torch.float32), ("raster", 224, 768, 2, torch.float32),
+                                               ("hilbert", 32, 256, 37, torch.float32)])
+def test_patch_embed_tiled_backward(ops, curve, img, D, B, xdt):
+    """dW and dbias of the tiled gather kernels (row segments straight into k-major LDS images, per-class partial
+    gradients un-permuted by the reduction) against the generic pixel-table kernels and fp32 torch math."""
+    from sfcvit.tokenizers.embeddings import _pixel_table
+    from sfcvit.curves import curve_table, hilbert_curve, z_curve
+    g = torch.Generator(device="cuda").manual_seed(22)
+    flat = np.arange(img * img, dtype=np.int32) if curve == "raster" else curve_table({"hilbert": hilbert_curve, "z": z_curve}[curve], img)
+    pix_h = _pixel_table(flat, img, 1, 256)
+    pix = torch.from_numpy(pix_h).cuda()
+    desc = ops.tile_descriptor(pix_h, img, "cuda")
+    N = pix.shape[0]
+    x = torch.randn(B, 3, img, img, device="cuda", generator=g).to(xdt)
+    dy = bf(torch.randn(B, N, D, device="cuda", generator=g))
+    dw, db = ops.patch_embed_bwd(x, pix, dy, D, True, desc)
+    dw_g, db_g = ops.patch_embed_bwd(x.to(torch.bfloat16), pix, dy, D, True, None)
+    close(dw, dw_g, rel=1 / 256, abs_scale=1 / 256)
+    close(db, db_g, rel=1e-4, abs_scale=1e-4)
+    tok = x.to(torch.bfloat16).float().reshape(B, 3, img * img)[:, :, pix.long()].permute(0, 2, 3, 1).reshape(B * N, 768)
+    ref = dy.float().reshape(B * N, D).t() @ tok
+    close(dw, ref, rel=1 / 200, abs_scale=1 / 200)
+    dw2, _ = ops.patch_embed_bwd(x, pix, dy, D, True, desc)
+    assert torch.equal(dw, dw2)
