@@ -23,6 +23,7 @@
 // (src/tokenizers/_1D/hilbert_embedding1D.py:30-44, morton_embedding1D.py:30-44, zigzag_embedding1D.py:30-39).
 #include "common_host.h"
 #include "device_common.h"
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -211,8 +212,10 @@ __global__ __launch_bounds__(PT) void pe2_bwd_kernel(const void *__restrict__ x,
     const int ncls = desc[1], sstep = desc[3], N = desc[4], K = C * 256;
     const int32_t *toks = desc + DESC_HDR, *origin = desc + DESC_HDR + N;
     const int NDT = D / 256, tiles = NDT * C;
-    // unit -> (class, row range z, d tile, channel)
-    int u = blockIdx.x, cls = -1, cnt = 0, tok0 = 0, z = 0, ubase = 0;
+    // unit -> (class, row range z, d tile, channel).  The tiles of one row range (same image rows, same dY rows) run on
+    // ONE XCD (blocks b, b + 8, ... share one): they re-read each other's operands from its L2 instead of from memory.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    int u = ((idx / tiles) * 8 + xcd) * tiles + idx % tiles, cls = -1, cnt = 0, tok0 = 0, z = 0, ubase = 0;
     for (int c = 0; c < ncls; c++) {
         const int t0 = desc[6 + c], n_c = desc[6 + c + 1] - t0, nz = (n_c * B + KR - 1) / KR;
         if (u < nz * tiles) { cls = c; cnt = n_c; tok0 = t0; z = u / tiles; u -= z * tiles; break; }
@@ -334,10 +337,19 @@ __global__ __launch_bounds__(256) void pe2_bwd_reduce(const float *__restrict__ 
 
 constexpr int PE2_BWD_LDS = 2 * 4 * BW_IMG;
 
-int pe2_bwd_row_range(int M) {                   // rows per unit: ~256 units for D = 768, C = 3
-    int kr = (9 * M + 255) / 256;
-    kr = (kr + BW_ROWS - 1) / BW_ROWS * BW_ROWS;
-    return kr < 256 ? 256 : kr;
+// Rows per unit: the smallest multiple of 64 for which the row ranges of all classes number at most G = 8 x (32 / tiles):
+// every XCD then holds whole groups (the `tiles` output tiles of one row range) on its 32 CUs in ONE round.
+int pe2_bwd_row_range(int B, int ncls, const int32_t *cnt, int tiles, int *nz_out) {
+    const int G = 8 * std::max(1, 32 / tiles);
+    int64_t M = 0;
+    for (int c = 0; c < ncls; c++) M += int64_t(cnt[c]) * B;
+    int kr = int((M / G + BW_ROWS - 1) / BW_ROWS * BW_ROWS);
+    if (kr < BW_ROWS) kr = BW_ROWS;
+    for (;; kr += BW_ROWS) {
+        int nz = 0;
+        for (int c = 0; c < ncls; c++) nz += int((int64_t(cnt[c]) * B + kr - 1) / kr);
+        if (nz <= G) { *nz_out = nz; return kr; }
+    }
 }
 
 constexpr int PE2_LDS = 2 * A_BYTES + 2 * B_BYTES + TM * int(sizeof(RowInfo));
@@ -378,16 +390,15 @@ int pe2_fwd(const sfcvit_patch_embed_args &a, hipStream_t s) {
 
 // Tiled backward: -1 = not eligible.  Workspace: fp32 slabs, one [D][C*256] per (class, row range).
 int64_t pe2_bwd_workspace(int B, int C, int N, int D) {
-    const int M = B * N, KR = pe2_bwd_row_range(M);
-    return (int64_t(M / KR) + 2 * MAXCLS) * D * C * 256 * int64_t(sizeof(float));
+    const int tiles = (D / 256) * C;
+    return int64_t(8 * std::max(1, 32 / tiles)) * D * C * 256 * int64_t(sizeof(float));      // at most G slabs
 }
 
 int pe2_bwd(const sfcvit_patch_embed_args &a, hipStream_t s) {
     if (!a.desc || a.P != 256 || a.D % 256 || a.desc_ncls <= 0 || a.desc_ncls > MAXCLS) return -1;
     if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.HW & 7)) return -1;
-    const int KR = pe2_bwd_row_range(a.B * a.N);
     int nz = 0;
-    for (int c = 0; c < a.desc_ncls; c++) nz += int((int64_t(a.desc_cnt[c]) * a.B + KR - 1) / KR);
+    const int KR = pe2_bwd_row_range(a.B, a.desc_ncls, a.desc_cnt, (a.D / 256) * a.C, &nz);
     const int64_t need = int64_t(nz) * a.D * a.C * 256 * int64_t(sizeof(float));
     if (!a.workspace || a.workspace_bytes < need) return -1;
     static bool attr = false;
@@ -398,7 +409,7 @@ int pe2_bwd(const sfcvit_patch_embed_args &a, hipStream_t s) {
         attr = true;
     }
     float *slabs = static_cast<float *>(a.workspace);
-    dim3 grid(unsigned(nz) * unsigned((a.D / 256) * a.C)), block(PT);
+    dim3 grid(unsigned((nz + 7) / 8) * 8u * unsigned((a.D / 256) * a.C)), block(PT);      // row ranges dealt to the 8 XCD slots
     if (a.x_is_bf16)
         hipLaunchKernelGGL(pe2_bwd_kernel<true>, grid, block, PE2_BWD_LDS, s, a.x, a.desc, static_cast<const uint16_t *>(a.y), slabs, a.B, a.C, a.HW, a.D, KR);
     else
