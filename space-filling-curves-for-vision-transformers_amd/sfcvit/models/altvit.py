@@ -20,13 +20,14 @@ def pair(t):
 
 
 def posemb_sincos_1d(n_pos, dim, temperature: float = 10000.0, dtype=torch.float32):
-    """altvit.py:16-41."""
-    pe = torch.zeros(n_pos, dim, dtype=dtype)
-    position = torch.arange(n_pos, dtype=dtype).unsqueeze(1)
-    div_term = torch.exp(torch.arange(0, dim, 2, dtype=dtype) * (-math.log(temperature) / dim))
-    pe[:, 0::2] = torch.sin(position * div_term)
-    pe[:, 1::2] = torch.cos(position * div_term)
-    return pe
+    """Sinusoidal table of the reference's SimpleViT (altvit.py:16-41): column 2i = sin(p w_i), column 2i + 1 = cos(p w_i),
+    w_i = temperature^(-2i / dim).  Angles are formed in float64 and the table is rounded once."""
+    if dim % 2:
+        raise ValueError("posemb_sincos_1d: dim must be even")
+    freq = torch.pow(torch.tensor(float(temperature), dtype=torch.float64),
+                     -torch.arange(0, dim, 2, dtype=torch.float64) / dim)                  # [dim / 2]
+    angle = torch.outer(torch.arange(n_pos, dtype=torch.float64), freq)                      # [n_pos, dim / 2]
+    return torch.stack((angle.sin(), angle.cos()), dim=-1).reshape(n_pos, dim).to(dtype)    # interleave sin / cos
 
 
 def _patches(x, p1, p2):
@@ -173,13 +174,12 @@ class HilbertViT(_PooledViT):
         N = int(math.sqrt(n))
         assert N * N == n, "Hilbert indices must form a square grid."
         assert dim % 2 == 0, "Feature dimension must be even."
-        pos = hilbert_indices.to(torch.float32).unsqueeze(1)
-        i_ar = torch.arange(dim // 2, dtype=torch.float32).unsqueeze(0)
-        two_pi = 2 * math.pi
-        scale = (2.0 * i_ar * N ** 2 * pos * two_pi) / (T * n * dim)
-        phase = h_param * (2.0 * i_ar * pos * two_pi) / dim
-        arg = scale + phase
-        self.register_buffer("pos_embedding", torch.cat([torch.sin(arg), torch.cos(arg)], dim=1).type(torch.float32))
+        # altvit.py:229-251 adds two phase terms per (position h, frequency i): 2 pi (2i) h N^2 / (T n dim) and
+        # 2 pi h_param (2i) h / dim.  With n = N^2 they are one product, angle = h * i * (4 pi / dim) * (1 / T + h_param);
+        # first half of the feature axis = sin, second half = cos.
+        rate = (4.0 * math.pi / dim) * (1.0 / T + h_param) * torch.arange(dim // 2, dtype=torch.float64)
+        angle = hilbert_indices.to(torch.float64).reshape(-1, 1) * rate.reshape(1, -1)
+        self.register_buffer("pos_embedding", torch.cat((angle.sin(), angle.cos()), dim=1).to(torch.float32))
         self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim)
         self.pool = "mean"
         self.to_latent = nn.Identity()
