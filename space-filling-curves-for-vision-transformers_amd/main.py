@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--checkpoint-dir", default="./vit_checkpoints")
     ap.add_argument("--resume", default=None)
+    ap.add_argument("--resume-model-only", action="store_true",
+                    help="take only the weights from --resume (e.g. a checkpoint the REFERENCE's main.py wrote: its "
+                         "optimizer / scheduler states are torch.optim formats, see INTEGRATION.md)")
     a = ap.parse_args()
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
@@ -114,12 +117,19 @@ def main():
     start_epoch, best = 0, 0.0
     if a.resume:
         ck = torch.load(a.resume, map_location=device, weights_only=True)
-        model.load_state_dict(ck["model_state_dict"])
-        if ck.get("optimizer_state_dict"):
-            optimizer.load_state_dict(ck["optimizer_state_dict"])              # fp32 master weights + Adam moments
-        start_epoch, best = ck["epoch"] + 1, ck.get("test_acc", 0.0)
-        scheduler.n = ck.get("scheduler_state_dict", {}).get("n", start_epoch * len(train_loader))
-        optimizer.lr = scheduler.lr_at(scheduler.n)
+        # the reference saves the torch.compile wrapper's state_dict: same keys behind an "_orig_mod." prefix
+        msd = {(k[len("_orig_mod."):] if k.startswith("_orig_mod.") else k): v for k, v in ck["model_state_dict"].items()}
+        model.load_state_dict(msd)
+        osd = ck.get("optimizer_state_dict") or {}
+        ours = "active" in osd and "master" in osd           # this repository's flat fp32 state (FusedAdamW.state_dict)
+        if osd and not ours and not a.resume_model_only:
+            print("--resume: the optimizer state is not FusedAdamW's (a reference checkpoint?): weights restored, "
+                  "optimizer and schedule start fresh (INTEGRATION.md, Checkpoints)")
+        if ours and not a.resume_model_only:
+            optimizer.load_state_dict(osd)                                     # fp32 master weights + Adam moments
+            start_epoch, best = ck["epoch"] + 1, ck.get("test_acc", 0.0)
+            scheduler.n = ck.get("scheduler_state_dict", {}).get("n", start_epoch * len(train_loader))
+            optimizer.lr = scheduler.lr_at(scheduler.n)
     os.makedirs(a.checkpoint_dir, exist_ok=True)
     ckpt = os.path.join(a.checkpoint_dir, f"checkpoint_{a.tokenizer}.pt")
 
@@ -127,6 +137,10 @@ def main():
         tr_loss, tr_acc = train_with_mixup_or_cutmix(model, train_loader, train_criterion, optimizer, scheduler,
                                                      device, reducer=reducer)
         te_loss, te_acc = evaluate(model, test_loader, test_criterion, device)
+        if world > 1:                                  # equal shards per rank: the global figures are the rank means
+            t = torch.tensor([tr_loss, tr_acc, te_loss, te_acc], device=device, dtype=torch.float64)
+            dist.all_reduce(t)
+            tr_loss, tr_acc, te_loss, te_acc = (t / world).tolist()
         if rank == 0:
             print(f"Epoch {epoch + 1}/{a.epochs} | Train Loss: {tr_loss:.4f}, Train Acc: {tr_acc:.4f} | "
                   f"Test Loss: {te_loss:.4f}, Test Acc: {te_acc:.4f}")            # main.py:331-335
