@@ -24,6 +24,7 @@
 //   * rows >= N: the DMA fills them with copies of row N - 1 (finite); padded queries get lse = +inf (P = dS = 0), padded
 //     keys get dS = 0 before the exchange and their dK / dV rows are not stored; exchange rows of keys >= 16 nf are
 //     zeroed once.
+#include <algorithm>
 #include "attention_common.h"
 #include "common_host.h"
 
@@ -33,6 +34,9 @@ namespace {
 using namespace attn;
 
 constexpr int FT = 1024, FWAVES = 16, FMAXC = 7;   // threads, waves, 32-row chunks (N <= 224)
+constexpr int FUSED_ROW_BYTES = 3 * 128 + 2 * 64 + 3 * 4;    // LDS bytes per padded sequence row
+constexpr int FUSED_POST_BYTES = 16384;                      // reused after the loop (short sequences: the allocation's floor)
+constexpr int FUSED_EXTRA = 256;                             // + 64 column sums of dQ
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -69,7 +73,9 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     char *qimg = smem, *doimg = smem + npad * 128, *kimg = smem + 2 * npad * 128, *dsb = smem + 3 * npad * 128;
     float *lse_s = reinterpret_cast<float *>(dsb + 2 * npad * 64), *del_s = lse_s + npad;
     uint32_t *rkey_s = reinterpret_cast<uint32_t *>(del_s + npad);   // dropout row key of every query
-    float *qcs = reinterpret_cast<float *>(rkey_s + npad);           // [64] column sums of dQ (dQ waves)
+    // after the loop the images are dead and the first 16 KiB of LDS are reused: [FWAVES][128] column-sum staging and the
+    // [32][64] partial dK / dV of a shared fragment; the dQ column sums live behind everything (FUSED_POST_BYTES)
+    float *qcs = reinterpret_cast<float *>(smem + max(npad * FUSED_ROW_BYTES, FUSED_POST_BYTES));   // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y, h = blockIdx.x, N = a.N, D = a.H * HD, ld = 3 * D;
     const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
@@ -77,10 +83,17 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     const uint16_t *dop = static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD;
     const float *lse = a.lse + (size_t(b) * a.H + h) * N;
     const int nf = NFC ? NFC : (N + 15) >> 4, nc = NFC ? ((NFC + 1) >> 1) : npad >> 5;
-    const bool is_key = wave < nf, is_dq = wave >= FWAVES - 2;
+    // Key fragments -> waves.  With nf <= 13 a wave is spare, and the LAST fragment (at N = 196: 4 valid keys of 16, a
+    // whole wave's VALU work all the same) is shared by waves nf - 1 and nf, one query fragment of every chunk each: the
+    // loop is VALU-bound per SIMD, waves go to SIMDs round-robin, and 13 whole fragments put 4 on one SIMD and 3 on the
+    // others -- halves make it 3.5 / 3.5 / 3 / 3.  The two partial dK / dV meet in LDS after the loop.
+    const bool split = nf <= FWAVES - 3;
+    const int kfi = (split && wave == nf) ? nf - 1 : wave;             // the key fragment this wave works on
+    const int tsel = !split ? -1 : wave == nf - 1 ? 0 : wave == nf ? 1 : -1;   // -1: both query fragments of a chunk
+    const bool is_key = wave < nf || (split && wave == nf), is_dq = wave >= FWAVES - 2;
     bf16x8 kf[2], vf[2];                              // this wave's 16 keys: V from HBM here, K from the staged image below
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) vf[kk] = global_frag(vp, ld, 16 * wave, is_key ? N : 0, kk, lane);
+    for (int kk = 0; kk < 2; kk++) vf[kk] = global_frag(vp, ld, 16 * kfi, is_key ? N : 0, kk, lane);
     // O, for delta: the 16-byte piece that pairs with this thread's piece(s) of the dO image (same row, same swizzled chunk)
     u32x4 opiece[2];
 #pragma unroll
@@ -133,10 +146,10 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     const float dsc = 1.f / (1.f - a.dropout_p);
     uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
     const int g = lane >> 4, li = lane & 15;
-    const int key = 16 * wave + li;                   // key waves: the key this lane's accumulator columns belong to
+    const int key = 16 * kfi + li;                    // key waves: the key this lane's accumulator columns belong to
     if (is_key) {                                     // rows >= N of the image copy row N - 1: those keys are masked below
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) kf[kk] = kc_frag_at(kimg, 16 * wave, (k_off ^ (kk << 6)));
+        for (int kk = 0; kk < 2; kk++) kf[kk] = kc_frag_at(kimg, 16 * kfi, (k_off ^ (kk << 6)));
     } else {
         kf[0] = kf[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
@@ -153,6 +166,10 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const int qf = 2 * c + t;
+                if (tsel == 1 - t) {                                  // the other wave of a shared fragment does this one
+                    p[t] = ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    continue;
+                }
                 f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
                     p[t][r] = pv * keep;
                     ds[t][r] = pv * (dp[r] * keep - del4[r]);             // x scale at the stores of dK and dQ
                 }
-                if (16 * wave + 16 > N) {                            // boundary fragment (wave-uniform): keys >= N carry no gradient
+                if (16 * kfi + 16 > N) {                             // boundary fragment (wave-uniform): keys >= N carry no gradient
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         if (key >= N) ds[t][r] = 0.f;
@@ -184,8 +201,8 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
             const bf16x8 pf = pack_frag(p[0], p[1]), dsf = pack_frag(ds[0], ds[1]);
             {   // dS^T for the dQ waves: 4 consecutive queries of fragment t = 8 bytes
                 const u32x4 w = __builtin_bit_cast(u32x4, dsf);
-                *reinterpret_cast<u32x2 *>(slot + ds_w) = u32x2{w[0], w[1]};
-                *reinterpret_cast<u32x2 *>(slot + (ds_w ^ 32)) = u32x2{w[2], w[3]};
+                if (tsel != 1) *reinterpret_cast<u32x2 *>(slot + ds_w) = u32x2{w[0], w[1]};
+                if (tsel != 0) *reinterpret_cast<u32x2 *>(slot + (ds_w ^ 32)) = u32x2{w[2], w[3]};
             }
 #pragma unroll
             for (int hf = 0; hf < 4; hf++) {
@@ -248,7 +265,32 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         }
         __syncthreads();
     }
-    if (is_key) {
+    if (split) {                                      // the shared fragment: wave nf hands its partial dK / dV to wave nf - 1
+        float *px = reinterpret_cast<float *>(smem) + FWAVES * 128;    // [32][64] lane-private words, behind the column-sum area
+        if (wave == nf) {
+            mfma_fence();
+#pragma unroll
+            for (int hf = 0; hf < 4; hf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    px[(4 * hf + r) * 64 + lane] = dk[hf][r];
+                    px[(16 + 4 * hf + r) * 64 + lane] = dv[hf][r];
+                }
+        }
+        __syncthreads();
+        if (wave == nf - 1) {
+            mfma_fence();
+#pragma unroll
+            for (int hf = 0; hf < 4; hf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    dk[hf][r] += px[(4 * hf + r) * 64 + lane];
+                    dv[hf][r] += px[(16 + 4 * hf + r) * 64 + lane];
+                }
+        }
+    }
+    const bool owns = wave < nf;                      // the wave that holds a fragment's complete dK / dV
+    if (owns) {
         mfma_fence();
         store_rows(dbase + D, ld, key, key < N, dk, scale, lane);
         store_rows(dbase + 2 * D, ld, key, key < N, dv, 1.f, lane);
@@ -258,8 +300,8 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         // (DPP reduction), the 13 key waves / 2 dQ waves meet in LDS (the exchange image is free now) and are summed in
         // a fixed order: bit-reproducible.  Layout of the partials: [batch][q | k | v thirds of 3 D], summed over
         // the batch afterwards (launch_colsum_reduce).
-        float *cs = reinterpret_cast<float *>(dsb);              // [FWAVES][128]
-        if (is_key) {
+        float *cs = reinterpret_cast<float *>(smem);             // [FWAVES][128]
+        if (owns) {
 #pragma unroll
             for (int hf = 0; hf < 4; hf++)
 #pragma unroll
@@ -284,8 +326,6 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
 }
 
 constexpr int FUSED_MAX_N = 32 * FMAXC;
-constexpr int FUSED_ROW_BYTES = 3 * 128 + 2 * 64 + 3 * 4;    // LDS bytes per padded sequence row
-constexpr int FUSED_EXTRA = 256;                             // + 64 column sums of dQ
 constexpr int FUSED_MAX_LDS = FUSED_MAX_N * FUSED_ROW_BYTES + FUSED_EXTRA;
 
 }  // namespace
@@ -304,7 +344,7 @@ int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s) {
         done = true;
     }
     const int npad = (a.N + 31) / 32 * 32;
-    const size_t lds = size_t(npad) * FUSED_ROW_BYTES + FUSED_EXTRA;
+    const size_t lds = size_t(std::max(npad * FUSED_ROW_BYTES, FUSED_POST_BYTES)) + FUSED_EXTRA;
     const bool nf13 = (a.N + 15) / 16 == 13, drop = a.dropout_p > 0.f;
     const dim3 grid(a.H, a.B), block(FT);
     if (nf13 && drop) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<13, true>), grid, block, lds, s, a, npad);
