@@ -272,6 +272,7 @@ def main():
     if not (loss_v == loss_v):
         raise SystemExit("loss is NaN")
 
+    rccl_stats = reducer.stats(args.steps) if reducer is not None else None     # collective calls inside: every rank
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * batch * args.steps / dt
@@ -292,7 +293,7 @@ def main():
             "final_loss": round(loss_v, 4),
         }
         if world > 1:
-            out["rccl"] = dict(reducer.stats(args.steps), backend=backend, world_size=dist.get_world_size())
+            out["rccl"] = dict(rccl_stats, backend=backend, world_size=dist.get_world_size())
         if kern:
             tsteps = len(range(0, args.steps, max(1, args.time_every)))     # steps whose launches carried event pairs
             traffic, traffic_build = load_traffic(args.workload)
