@@ -213,28 +213,50 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
     }
 }
 
-// Sum of the per-block partials [nblocks][3][D] (dgamma | dbeta | column sums of the outgoing
-// gradient): 16 columns x 16 partial-groups per block, fixed summation order (bitwise reproducible).
+// Sum of per-block partials, shared by ln_bwd_reduce and colsum_reduce_kernel: a 1024-thread block owns 16 columns;
+// its 64 thread rows each add every 64th partial row (<= 8 independent loads in flight per thread for 512 partials,
+// where the 16-row form these kernels had serialised 32), then 4 thread rows add 16 sub-sums each and one adds those
+// 4.  Fixed summation order, no float atomics: bit-reproducible.  The value is returned in thread row 0.
 __device__ __forceinline__ void store_grad(void *p, int i, float v, int as_bf16) {
     if (as_bf16) static_cast<uint16_t *>(p)[i] = f2bf(v);
     else static_cast<float *>(p)[i] = v;
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_reduce(const float *__restrict__ partial, void *__restrict__ dgamma,
-                                                    void *__restrict__ dbeta, void *__restrict__ dcol, int nblocks, int D,
-                                                    int as_bf16) {
-    __shared__ float red[16][17];
+constexpr int RED_THREADS = 1024;
+
+__device__ __forceinline__ float reduce_partials16(const float *__restrict__ part, int nparts, int ld, int c, bool ok) {
+    __shared__ float red[64][17];
+    __shared__ float red2[4][16];
     const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    if (c < 3 * D)
-        for (int b = grp; b < nblocks; b += 16) s += partial[size_t(b) * 3 * D + c];
+    if (ok) {
+        int b = grp;
+        for (; b + 192 < nparts; b += 256) {
+            const float v0 = part[size_t(b) * ld + c], v1 = part[size_t(b + 64) * ld + c];
+            const float v2 = part[size_t(b + 128) * ld + c], v3 = part[size_t(b + 192) * ld + c];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < nparts; b += 64) s += part[size_t(b) * ld + c];
+    }
     red[grp][cl] = s;
     __syncthreads();
-    if (grp == 0 && c < 3 * D) {
+    if (grp < 4) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; k++) t += red[k][cl];
+        for (int k = 0; k < 16; k++) t += red[grp * 16 + k][cl];
+        red2[grp][cl] = t;
+    }
+    __syncthreads();
+    return grp == 0 ? (red2[0][cl] + red2[1][cl]) + (red2[2][cl] + red2[3][cl]) : 0.f;
+}
+
+// [nblocks][3][D] partials -> dgamma | dbeta | column sums of the outgoing gradient.
+__global__ __launch_bounds__(RED_THREADS) void ln_bwd_reduce(const float *__restrict__ partial, void *__restrict__ dgamma,
+                                                            void *__restrict__ dbeta, void *__restrict__ dcol, int nblocks,
+                                                            int D, int as_bf16) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const float t = reduce_partials16(partial, nblocks, 3 * D, c, c < 3 * D);
+    if (threadIdx.x < 16 && c < 3 * D) {
         if (c < D) store_grad(dgamma, c, t, as_bf16);
         else if (c < 2 * D) store_grad(dbeta, c - D, t, as_bf16);
         else if (dcol) store_grad(dcol, c - 2 * D, t, as_bf16);
@@ -284,23 +306,12 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(const uint16_t *__restr
     }
 }
 
-// out[c] = sum over row blocks in a fixed order (no float atomics: bit-reproducible).  A block owns 32 columns;
-// its 8 thread rows each add every 8th partial, then the 8 sub-sums are added in order.
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ part, int nparts, int N,
-                                                            void *__restrict__ out, int as_bf16) {
-    __shared__ float red[8][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), s = threadIdx.x >> 5;
-    float t = 0.f;
-    if (c < N)
-        for (int y = s; y < nparts; y += 8) t += part[size_t(y) * N + c];
-    red[s][threadIdx.x & 31] = t;
-    __syncthreads();
-    if (s == 0 && c < N) {
-        float r = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; k++) r += red[k][threadIdx.x];
-        store_grad(out, c, r, as_bf16);
-    }
+// out[c] = sum over row blocks in a fixed order (reduce_partials16 above).
+__global__ __launch_bounds__(RED_THREADS) void colsum_reduce_kernel(const float *__restrict__ part, int nparts, int N,
+                                                                   void *__restrict__ out, int as_bf16) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const float t = reduce_partials16(part, nparts, N, c, c < N);
+    if (threadIdx.x < 16 && c < N) store_grad(out, c, t, as_bf16);
 }
 
 // ---------------------------------------------------------------------------
@@ -612,7 +623,7 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D);
     else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D);
     if (int rc = check_launch("layernorm_bwd")) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((3 * D + 15) / 16), dim3(256), 0, s, part, dgamma, dbeta, dcol, nb, D, grads_bf16);
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((3 * D + 15) / 16), dim3(RED_THREADS), 0, s, part, dgamma, dbeta, dcol, nb, D, grads_bf16);
     return check_launch("layernorm_bwd_reduce");
 }
 
@@ -636,7 +647,7 @@ void colsum_plan(int M, int N, int &col_blocks, int &row_blocks, int &rpb) {
 
 namespace sfcvit {
 int launch_colsum_reduce(const float *part, int nparts, int N, void *out, int out_bf16, void *stream) {
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream), part, nparts, N,
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 15) / 16), dim3(RED_THREADS), 0, static_cast<hipStream_t>(stream), part, nparts, N,
                        out, out_bf16);
     return check_launch("colsum reduce");
 }
@@ -663,7 +674,7 @@ extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, void *out, int
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(THREADS), 0, s,
                        static_cast<const uint16_t *>(x), M, N, ld, rpb, part);
     if (int rc = check_launch("colsum")) return rc;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, s, part, row_blocks, N, out, out_bf16);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 15) / 16), dim3(RED_THREADS), 0, s, part, row_blocks, N, out, out_bf16);
     return check_launch("colsum reduce");
 }
 
