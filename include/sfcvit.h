@@ -116,6 +116,43 @@ int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *stream);
 int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Fused hierarchical tokenizer, forward
+ *   replaces HierarchicalHilbertEmbedding.forward (src/tokenizers/multiscale/multi_hilbert.py:31-40) and its
+ *   siblings multi_morton.py / multi_moore.py / multi_peano.py / multi_onion.py / multi_zigzag.py (same lines) when
+ *   every level has the same token count N (true of every configuration the reference ships, main.py:269-274; the
+ *   F.interpolate(mode='linear') to N tokens is then the identity):
+ *       h[m, l*D:(l+1)*D] = bf16( W_l tokens_l[m, :] + b_l )      level l = SFCEmbedding1D (multi_hilbert.py:74-84)
+ *       y[m, :]           = bf16( Wf h[m, :] + bf )               fusion  = nn.Linear(L*D, L*D)
+ *   in ONE kernel: tokens gathered through the per-level pixel tables, level outputs kept in LDS as the A operand
+ *   of the fusion GEMM.  h is also written out (the fusion weight gradient needs it); backward composes
+ *   sfcvit_gemm (dh, dWf) and sfcvit_patch_embed_bwd per level.
+ *   wf = NULL: the kernel stops after the first line -- gather + every level projection + the concatenation (each
+ *   level writes its own columns of h; no torch.cat pass) -- and the caller runs the fusion Linear as sfcvit_gemm.
+ *   That pair is the faster one at the reference's shape (the all-in-one kernel re-streams Wf once per
+ *   64 token rows and is bound by L2 -> CU delivery); both are kept, bit-identical in h.
+ * ---------------------------------------------------------------------- */
+#define SFCVIT_HIER_MAX_LEVELS 4
+typedef struct sfcvit_hier_args {
+    const void *x;                               /* [B, C, H*W] image, fp32 (x_is_bf16 = 0) or bf16 */
+    const int32_t *pix[SFCVIT_HIER_MAX_LEVELS];  /* level l: [N, P[l]] pixel offsets (sfcvit_pixel_table), device */
+    const void *w[SFCVIT_HIER_MAX_LEVELS];       /* level l: [D, P[l]*C] bf16, feature index kk*C + c, 16-byte aligned */
+    const void *b[SFCVIT_HIER_MAX_LEVELS];       /* level l: [D] bf16 or NULL */
+    const void *wf;                              /* [L*D, L*D] bf16; NULL = levels + concatenation only (y unused) */
+    const void *bf;                              /* [L*D] bf16 or NULL */
+    void *h;                                     /* out [B*N, L*D] bf16: concatenated level outputs */
+    void *y;                                     /* out [B*N, L*D] bf16 */
+    int32_t P[SFCVIT_HIER_MAX_LEVELS];           /* pixels per token of level l; N * P[l] = H*W for every level */
+    int32_t B, C, HW, N, L, D;
+    int32_t x_is_bf16;
+} sfcvit_hier_args;
+
+/* HOST: 1 if (L, D, C, P[0..L)) is inside the fused kernel's envelope: 1..4 levels, D % 64 == 0, L*D % 256 == 0,
+ * P[l]*C % 8 == 0, and 64 rows of (L*D + sum of P[l]*C) bf16 fit the 160 KiB LDS; else 0 (compose the level calls). */
+int sfcvit_hier_tokenizer_supported(int L, int D, int C, const int32_t *P);
+/* SFCVIT_EINVAL outside that envelope or when the levels do not share the token count. */
+int sfcvit_hier_tokenizer_fwd(const sfcvit_hier_args *a, void *stream);
+
+/* ------------------------------------------------------------------------
  * bf16 MFMA GEMM with fused epilogue
  *   replaces nn.Linear forward/backward at every site of the path:
  *   in_proj / out_proj (torch:nn/functional.py:5822-5833,6632-6637), linear1/linear2

@@ -31,7 +31,11 @@ CURVE_KINDS = ("hilbert", "z", "moore", "peano")
 HIER_CASES = {
     "hier_morton32": (32, 3, [16, 4, 1], 64, "z", 3),       # the shape of the reference's main.py:269-274 default
     "hier_hilbert32_resample": (32, 3, [4, 4], 32, "hilbert", 2),   # 256 and 64 tokens: exercises the linear resampling
+    # inside the fused kernel's envelope (csrc/hier_tokenizer.hip: one token count, L*D % 256 == 0):
+    "hier_morton32_d256": (32, 3, [16, 4, 1], 256, "z", 3),          # main.py:269-274 literally: 3 x 256 -> 768, 64 tokens
+    "hier_hilbert32_4lvl": (32, 3, [64, 16, 4, 1], 64, "hilbert", 3),   # 4 levels of 192 features, 16 tokens: 48 rows
 }
+HIER_FUSED_CASES = ("hier_morton32_d256", "hier_hilbert32_4lvl")
 
 # name -> (reference module, class, ctor args, kind, batch): the remaining tokenizers.
 #   kind = ("grouped", curve, p, g, buffer)       Linear over g pre-patches of p x p pixels in `curve` order

@@ -333,16 +333,11 @@ constexpr int FUSED_MAX_LDS = FUSED_MAX_N * FUSED_ROW_BYTES + FUSED_EXTRA;
 // -1: not eligible (the caller falls back to the two-kernel form); else a status.
 int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s) {
     if (a.hd != HD || a.N > FUSED_MAX_N) return -1;
-    static bool done = false;
-    if (!done) {
-        for (const void *k : {reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<0, false>),
-                              reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<0, true>),
-                              reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<13, false>),
-                              reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<13, true>)})
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_MAX_LDS) != hipSuccess)
-                return check_launch("attention_bwd_fused attribute");
-        done = true;
-    }
+    for (const void *k : {reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<0, false>),
+                          reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<0, true>),
+                          reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<13, false>),
+                          reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<13, true>)})
+        if (int rc = raise_lds_limit(k, FUSED_MAX_LDS, "attention_bwd_fused attribute")) return rc;
     const int npad = (a.N + 31) / 32 * 32;
     const size_t lds = size_t(std::max(npad * FUSED_ROW_BYTES, FUSED_POST_BYTES)) + FUSED_EXTRA;
     const bool nf13 = (a.N + 15) / 16 == 13, drop = a.dropout_p > 0.f;

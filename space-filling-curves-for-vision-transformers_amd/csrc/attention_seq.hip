@@ -331,14 +331,10 @@ constexpr int SEQ_MAX_N = 256;
 constexpr int SEQ_MAX_LDS = 2 * SEQ_MAX_N * 128 + 3 * SEQ_MAX_N * 4;
 
 int set_lds_limit() {
-    static bool done = false;
-    if (done) return SFCVIT_OK;
     for (const void *k : {reinterpret_cast<const void *>(&attn_seq_fwd_kernel<0>), reinterpret_cast<const void *>(&attn_seq_bwd_kv_kernel<0>),
                           reinterpret_cast<const void *>(&attn_seq_bwd_q_kernel<0>), reinterpret_cast<const void *>(&attn_seq_fwd_kernel<13>),
                           reinterpret_cast<const void *>(&attn_seq_bwd_kv_kernel<13>), reinterpret_cast<const void *>(&attn_seq_bwd_q_kernel<13>)})
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SEQ_MAX_LDS) != hipSuccess)
-            return check_launch("attention_seq attribute");
-    done = true;
+        if (int rc = raise_lds_limit(k, SEQ_MAX_LDS, "attention_seq attribute")) return rc;
     return SFCVIT_OK;
 }
 

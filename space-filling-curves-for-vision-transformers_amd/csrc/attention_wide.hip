@@ -305,25 +305,15 @@ constexpr int LDS_LIMIT = 160 * 1024;
 
 template <int S>
 int launch_fwd(const sfcvit_attn_args &a, int npad, size_t lds, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_wide_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT) != hipSuccess)
-            return check_launch("attention_wide attribute");
-        done = true;
-    }
+    if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&attn_wide_fwd_kernel<S>), LDS_LIMIT, "attention_wide attribute")) return rc;
     hipLaunchKernelGGL(attn_wide_fwd_kernel<S>, dim3(a.H, a.B), dim3(THREADS), lds, s, a, npad);
     return check_launch("attention_wide_fwd");
 }
 
 template <int S>
 int launch_bwd(const sfcvit_attn_args &a, int npad, size_t lds_kv, size_t lds_q, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
-        for (const void *k : {reinterpret_cast<const void *>(&attn_wide_bwd_kv_kernel<S>), reinterpret_cast<const void *>(&attn_wide_bwd_q_kernel<S>)})
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT) != hipSuccess)
-                return check_launch("attention_wide attribute");
-        done = true;
-    }
+    for (const void *k : {reinterpret_cast<const void *>(&attn_wide_bwd_kv_kernel<S>), reinterpret_cast<const void *>(&attn_wide_bwd_q_kernel<S>)})
+        if (int rc = raise_lds_limit(k, LDS_LIMIT, "attention_wide attribute")) return rc;
     hipLaunchKernelGGL(attn_wide_bwd_kv_kernel<S>, dim3(a.H, a.B), dim3(THREADS), lds_kv, s, a, npad);
     if (int rc = check_launch("attention_wide_bwd kv")) return rc;
     hipLaunchKernelGGL(attn_wide_bwd_q_kernel<S>, dim3(a.H, a.B), dim3(THREADS), lds_q, s, a, npad);

@@ -1,6 +1,7 @@
 #include "common_host.h"
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 namespace sfcvit {
 namespace {
@@ -23,6 +24,25 @@ int fail(int code, const char *fmt, ...) {
 }
 
 void clear_error() { g_err[0] = 0; }
+
+// hipFuncSetAttribute applies to the kernel on the CURRENT device only: one flag per (kernel, device).
+int raise_lds_limit(const void *kernel, int bytes, const char *what) {
+    struct Entry { const void *fn; uint64_t devs; };
+    static Entry table[128];
+    static int used = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(SFCVIT_ENODEV, "%s: no current HIP device", what);
+    std::lock_guard<std::mutex> lock(mu);
+    Entry *e = nullptr;
+    for (int i = 0; i < used && !e; i++)
+        if (table[i].fn == kernel) e = &table[i];
+    if (e && (e->devs >> dev & 1)) return SFCVIT_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return check_launch(what);
+    if (!e && used < 128) { e = &table[used++]; e->fn = kernel; e->devs = 0; }
+    if (e) e->devs |= uint64_t(1) << dev;          // a full table only costs the repeated (idempotent) call
+    return SFCVIT_OK;
+}
 
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

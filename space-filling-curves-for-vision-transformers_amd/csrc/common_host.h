@@ -13,6 +13,8 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();
 // hipGetLastError() -> SFCVIT_ELAUNCH with the HIP message, or SFCVIT_OK.
 int check_launch(const char *what);
+// Opt a kernel into `bytes` of dynamic LDS on the current device (once per kernel and device; 0 or an error code).
+int raise_lds_limit(const void *kernel, int bytes, const char *what);
 
 // Which GEMM kernel the calling thread's last sfcvit_gemm launched (sfcvit_last_gemm_kernel formats it as the symbol
 // rocprofv3 shows): family 1 gemm8p_kernel<a, b>, 2 gemm8p_km_kernel, 3 gemm256_kernel<a, b, c, d>, 4 gemm_kernel<a, b, c>.

@@ -191,13 +191,8 @@ __global__ __launch_bounds__(Cfg<BN_>::T, 2) void gemm256_kernel(const sfcvit_ge
 template <bool A_KM, bool B_KM, int BN_, bool HEAVY>
 int launch1(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s) {
     constexpr size_t lds = Cfg<BN_>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_kernel<A_KM, B_KM, BN_, HEAVY>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
-            return check_launch("gemm256 attribute");
-        attr_set = true;
-    }
+    if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm256_kernel<A_KM, B_KM, BN_, HEAVY>), int(lds), "gemm256 attribute"))
+        return rc;
     dim3 grid((a.M / 256) * (a.N / BN_), 1, splits), block(Cfg<BN_>::T);
     note_gemm_kernel(3, A_KM, B_KM, BN_, HEAVY);
     hipLaunchKernelGGL((gemm256_kernel<A_KM, B_KM, BN_, HEAVY>), grid, block, lds, s, a, k_per_split);

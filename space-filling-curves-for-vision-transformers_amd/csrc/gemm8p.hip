@@ -754,13 +754,7 @@ unsigned *queue_counters(hipStream_t s) {
 template <int NI, int MASK>
 int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
     const int LDS_TOTAL = LDS_BIAS + (a.bias ? a.N * 2 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess)
-            return check_launch("gemm8p attribute");
-        attr_set = true;
-    }
+    if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>), LDS_MAX, "gemm8p attribute")) return rc;
     unsigned *counters = queue_counters(s);
     if (!counters) return fail(SFCVIT_ELAUNCH, "gemm8p: could not allocate the tile-queue counters");
     note_gemm_kernel(1, NI, MASK);
@@ -804,13 +798,7 @@ int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_us
     int kps = ((KT + splits - 1) / splits + 1) / 2 * 2;           // k-tiles per split, even
     splits = (KT + kps - 1) / kps;
     if (splits < 2) return -1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8p_km_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess)
-            return check_launch("gemm8p_km attribute");
-        attr_set = true;
-    }
+    if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_km_kernel), LDS_BYTES, "gemm8p_km attribute")) return rc;
     note_gemm_kernel(2);
     hipLaunchKernelGGL(gemm8p_km_kernel, dim3((tiles * splits + 7) / 8 * 8), dim3(T), LDS_BYTES, s, a, kps, splits);
     *splits_used = splits;

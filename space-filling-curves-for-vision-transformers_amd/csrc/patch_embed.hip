@@ -191,17 +191,35 @@ __global__ __launch_bounds__(THREADS, 2) void pe_bwd_kernel(const Geo g, const u
     store_partial(acc, slabs + size_t(zz) * D * g.Kp, D, g.Kp, d0, f0, wm, wn, lane);
 }
 
-// dW[d][kk*C + c] = sum_z slab[z][d][c*P + kk]
-__global__ __launch_bounds__(256) void pe_bwd_reduce(const float *__restrict__ slabs, int splits, float *__restrict__ dw,
-                                                     int D, int C, int P, int Kp) {
-    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    const int K = C * P;
-    if (i >= int64_t(D) * K) return;
-    const int d = int(i / K), f = int(i % K);
-    const int c = f / P, kk = f % P;
+// dW[d][kk*C + c] = sum_z slab[z][d][c*P + kk].  A 1024-thread block owns 16 consecutive slab elements; its 64 thread
+// rows each add every 64th slab (a narrow tokenizer level -- K = 48, D = 256 -- has 2 output tiles and therefore 512
+// slabs: one thread per element summed them serially in 119 us), then 4 thread rows add 16 sub-sums each and one adds
+// those 4.  Fixed order: bit-reproducible.
+__global__ __launch_bounds__(1024) void pe_bwd_reduce(const float *__restrict__ slabs, int splits, float *__restrict__ dw,
+                                                      int D, int C, int P, int Kp) {
+    __shared__ float red[64][17];
+    __shared__ float red2[4][16];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t i = int64_t(blockIdx.x) * 16 + cl, total = int64_t(D) * Kp;
     float s = 0.f;
-    for (int z = 0; z < splits; z++) s += slabs[(size_t(z) * D + d) * Kp + f];
-    dw[size_t(d) * K + kk * C + c] = s;
+    if (i < total)
+        for (int z = grp; z < splits; z += 64) s += slabs[size_t(z) * total + i];
+    red[grp][cl] = s;
+    __syncthreads();
+    if (grp < 4) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += red[grp * 16 + k][cl];
+        red2[grp][cl] = t;
+    }
+    __syncthreads();
+    if (grp == 0 && i < total) {
+        const int K = C * P, d = int(i / Kp), f = int(i % Kp);
+        if (f < K) {
+            const int c = f / P, kk = f % P;
+            dw[size_t(d) * K + kk * C + c] = (red2[0][cl] + red2[1][cl]) + (red2[2][cl] + red2[3][cl]);
+        }
+    }
 }
 
 int bwd_splits(int M, int D, int K) {
@@ -299,8 +317,8 @@ extern "C" int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *st
     else
         hipLaunchKernelGGL(pe_bwd_kernel<false>, grid, block, lds, s, g, static_cast<const uint16_t *>(a->y), slabs, a->D, m_per_split);
     if (int rc = check_launch("patch_embed_bwd")) return rc;
-    const int64_t nw = int64_t(a->D) * g.K;
-    hipLaunchKernelGGL(pe_bwd_reduce, dim3(unsigned((nw + 255) / 256)), dim3(256), 0, s, slabs, zs,
+    const int64_t nw = int64_t(a->D) * g.Kp;
+    hipLaunchKernelGGL(pe_bwd_reduce, dim3(unsigned((nw + 15) / 16)), dim3(1024), 0, s, slabs, zs,
                        static_cast<float *>(a->dw), a->D, a->C, a->P, g.Kp);
     if (int rc = check_launch("patch_embed_bwd reduce")) return rc;
     if (a->dbias)

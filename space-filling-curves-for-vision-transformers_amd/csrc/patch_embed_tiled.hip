@@ -367,13 +367,8 @@ int pe2_fwd(const sfcvit_patch_embed_args &a, hipStream_t s) {
     hipLaunchKernelGGL(pe2_permute_w_kernel, dim3(1024), dim3(256), 0, s, static_cast<const uint16_t *>(a.w), a.desc + DESC_HDR + 2 * a.N,
                        wp, a.D, a.C, a.desc_ncls);
     if (int rc = check_launch("patch_embed_fwd (tiled) permute")) return rc;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pe2_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PE2_LDS) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&pe2_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PE2_LDS) != hipSuccess)
-            return check_launch("patch_embed_fwd (tiled) attribute");
-        attr = true;
-    }
+    for (const void *k : {reinterpret_cast<const void *>(&pe2_fwd_kernel<false>), reinterpret_cast<const void *>(&pe2_fwd_kernel<true>)})
+        if (int rc = raise_lds_limit(k, PE2_LDS, "patch_embed_fwd (tiled) attribute")) return rc;
     int n_row_tiles = 0;
     for (int c = 0; c < a.desc_ncls; c++) n_row_tiles += int((int64_t(a.desc_cnt[c]) * a.B + TM - 1) / TM);
     const int NCT = a.D / TN;
@@ -401,13 +396,8 @@ int pe2_bwd(const sfcvit_patch_embed_args &a, hipStream_t s) {
     const int KR = pe2_bwd_row_range(a.B, a.desc_ncls, a.desc_cnt, (a.D / 256) * a.C, &nz);
     const int64_t need = int64_t(nz) * a.D * a.C * 256 * int64_t(sizeof(float));
     if (!a.workspace || a.workspace_bytes < need) return -1;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pe2_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PE2_BWD_LDS) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&pe2_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PE2_BWD_LDS) != hipSuccess)
-            return check_launch("patch_embed_bwd (tiled) attribute");
-        attr = true;
-    }
+    for (const void *k : {reinterpret_cast<const void *>(&pe2_bwd_kernel<false>), reinterpret_cast<const void *>(&pe2_bwd_kernel<true>)})
+        if (int rc = raise_lds_limit(k, PE2_BWD_LDS, "patch_embed_bwd (tiled) attribute")) return rc;
     float *slabs = static_cast<float *>(a.workspace);
     dim3 grid(unsigned((nz + 7) / 8) * 8u * unsigned((a.D / 256) * a.C)), block(PT);      // row ranges dealt to the 8 XCD slots
     if (a.x_is_bf16)

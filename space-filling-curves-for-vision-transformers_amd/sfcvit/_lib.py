@@ -22,6 +22,13 @@ class PatchEmbedArgs(ctypes.Structure):
                 ("desc", c_void_p), ("desc_ncls", c_int32), ("desc_cnt", c_int32 * 8)]
 
 
+class HierArgs(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("pix", c_void_p * 4), ("w", c_void_p * 4), ("b", c_void_p * 4),
+                ("wf", c_void_p), ("bf", c_void_p), ("h", c_void_p), ("y", c_void_p),
+                ("P", c_int32 * 4), ("B", c_int32), ("C", c_int32), ("HW", c_int32), ("N", c_int32), ("L", c_int32),
+                ("D", c_int32), ("x_is_bf16", c_int32)]
+
+
 class GemmArgs(ctypes.Structure):
     _fields_ = [("a", c_void_p), ("b", c_void_p), ("c", c_void_p), ("bias", c_void_p),
                 ("residual", c_void_p), ("aux_in", c_void_p), ("aux_out", c_void_p),
@@ -60,6 +67,8 @@ SIGNATURES = {
     "sfcvit_pixel_table": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "sfcvit_tile_descriptors": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int]),
     "sfcvit_patch_embed_fwd": (c_int, [ctypes.POINTER(PatchEmbedArgs), c_void_p]),
+    "sfcvit_hier_tokenizer_supported": (c_int, [c_int, c_int, c_int, c_void_p]),
+    "sfcvit_hier_tokenizer_fwd": (c_int, [ctypes.POINTER(HierArgs), c_void_p]),
     "sfcvit_patch_embed_bwd": (c_int, [ctypes.POINTER(PatchEmbedArgs), c_void_p]),
     "sfcvit_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
     "sfcvit_gemm_workspace": (c_int64, [c_int, c_int, c_int]),

@@ -128,6 +128,62 @@ def patch_embed(x, pix, weight, bias, desc=None):
     return _PatchEmbed.apply(x, pix, _bf(weight), _bf(bias), desc)
 
 
+# SFCVIT_HIER_ONE_KERNEL=1: gather + levels + concatenation + fusion Linear in ONE kernel (csrc/hier_tokenizer.hip,
+# FUSE = true).  Default: the same kernel without its last phase (gather + levels + concatenation) followed by the
+# fusion Linear on the persistent 8-phase GEMM -- measured faster at the reference's shape.
+HIER_ONE_KERNEL = _os.environ.get("SFCVIT_HIER_ONE_KERNEL", "0") == "1"
+
+
+class _HierTokenizer(Function):
+    """Fused hierarchical tokenizer (ops.hier_tokenizer_fwd).  Saved for backward: the image (bf16, what the kernel's
+    gather rounds to anyway) and the concatenated level outputs h; backward is the chain rule on existing kernels:
+    dh = dy Wf, dWf = dy^T h, then per level the tokenizer weight gradient from that level's columns of dh."""
+
+    @staticmethod
+    def forward(ctx, x, wf, bf, n_levels, one_kernel, *rest):
+        pix = rest[:n_levels]
+        w = rest[n_levels:2 * n_levels]
+        b = rest[2 * n_levels:3 * n_levels]
+        x = _c(x if x.dtype == _BF16 else x.to(_BF16))
+        if one_kernel:
+            y, h = ops.hier_tokenizer_fwd(x, pix, w, b, wf, bf)
+        else:
+            _, h = ops.hier_tokenizer_fwd(x, pix, w, b, None, None)
+            y = ops.gemm(h.view(-1, h.shape[-1]), wf, bias=bf).view(h.shape)
+        ctx.save_for_backward(x, h, wf, *pix)
+        ctx.n_levels, ctx.params = n_levels, (w, b, bf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, wf = ctx.saved_tensors[:3]
+        pix = ctx.saved_tensors[3:]
+        w, b, bf = ctx.params
+        L = ctx.n_levels
+        E = h.shape[-1]
+        D = E // L
+        dy2, h2 = _c(dy).view(-1, E), h.view(-1, E)
+        dwf = _wgrad(dy2, h2, wf)
+        dbf = _bgrad(dy2, bf) if bf is not None else None
+        dh = ops.gemm_dx(dy2, wf).view(h.shape)
+        dws, dbs = [], []
+        for l in range(L):
+            dwl, dbl = ops.patch_embed_bwd(x, pix[l], _c(dh[..., l * D:(l + 1) * D]), D, want_bias=b[l] is not None)
+            dws.append(dwl.to(_BF16))
+            dbs.append(dbl.to(_BF16) if dbl is not None else None)
+        return (None, dwf, dbf, None, None) + (None,) * L + tuple(dws) + tuple(dbs)
+
+
+def hier_tokenizer(x, pix_list, weights, biases, fusion_weight, fusion_bias, one_kernel=None):
+    """y = fusion(concat_l(level_l(x))) for levels with one common token count (reference:
+    multiscale/multi_hilbert.py:31-40).  x [B,C,H,W] -> [B, N, L*D] bf16.  one_kernel: True = everything in one kernel,
+    False = fused gather + levels + concatenation, then the fusion Linear as a GEMM; None = HIER_ONE_KERNEL."""
+    L = len(pix_list)
+    one = HIER_ONE_KERNEL if one_kernel is None else bool(one_kernel)
+    return _HierTokenizer.apply(x, _bf(fusion_weight), _bf(fusion_bias), L, one, *pix_list, *[_bf(w) for w in weights],
+                                *[_bf(b) for b in biases])
+
+
 # ----------------------------------------------------------------------------
 class _Linear(Function):
     @staticmethod
@@ -443,7 +499,7 @@ def soft_target_cross_entropy(logits, targets):
 # as written.  What "reduce-overhead" is after (no per-launch host cost) is delivered for the whole training step by
 # sfcvit.training.GraphedTrainStep instead of per compiled region.
 # ----------------------------------------------------------------------------
-for _name in ("patch_embed", "linear", "layer_norm", "gelu", "attention", "mixer_block", "encoder_layer", "predictor_head",
+for _name in ("patch_embed", "hier_tokenizer", "linear", "layer_norm", "gelu", "attention", "mixer_block", "encoder_layer", "predictor_head",
               "soft_target_cross_entropy"):
     globals()[_name] = torch.compiler.disable(globals()[_name], recursive=True)
 del _name

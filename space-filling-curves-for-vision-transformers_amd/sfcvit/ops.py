@@ -459,6 +459,59 @@ def patch_embed_bwd(x, pix, dy, D, want_bias=True, desc=None):
     return dw, db
 
 
+def hier_tokenizer_supported(n_levels, D, C, pixels_per_token):
+    """Is (levels, level width, channels, pixels per token of each level) inside the fused hierarchical kernel's
+    envelope (sfcvit_hier_tokenizer_supported)?  Host arithmetic only."""
+    if not 1 <= n_levels <= 4 or len(pixels_per_token) != n_levels:
+        return False
+    P = (ctypes.c_int32 * 4)(*pixels_per_token)
+    return bool(lib.sfcvit_hier_tokenizer_supported(n_levels, D, C, P))
+
+
+def hier_tokenizer_fwd(x, pix_list, w_list, b_list, wf, bf):
+    """Fused hierarchical tokenizer (csrc/hier_tokenizer.hip): x [B,C,H,W] fp32/bf16; per level pix [N,P_l] int32,
+    w [D,P_l*C] bf16, b [D] bf16 or None; wf [L*D,L*D], bf [L*D] or None -> (y [B,N,L*D] bf16, h [B,N,L*D] bf16).
+    wf = None: gather + level projections + concatenation only -> (None, h); the caller applies the fusion Linear."""
+    L = len(pix_list)
+    if not x.is_cuda:
+        raise _lib.SfcvitError("hier_tokenizer: the HIP path needs a CUDA (ROCm) tensor; there is no CPU fallback")
+    _cur_dev(x, "hier_tokenizer x")
+    if x.dtype not in (torch.float32, _BF16) or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError(f"hier_tokenizer x: expected contiguous [B,C,H,W] fp32/bf16, got {x.dtype} {tuple(x.shape)}")
+    B, C, H, W = x.shape
+    N = pix_list[0].shape[0]
+    D = w_list[0].shape[0]
+    E = L * D
+    a = _lib.HierArgs()
+    a.x, a.x_is_bf16 = x.data_ptr(), int(x.dtype == _BF16)
+    flops = 2.0 * B * N * E * E if wf is not None else 0.0
+    for l in range(L):
+        pix = _need(pix_list[l], torch.int32, "hier_tokenizer pix", 2)
+        if pix.shape[0] != N:
+            raise ValueError("hier_tokenizer: every level must have the same token count")
+        w = _need(w_list[l], _BF16, "hier_tokenizer w", 2)
+        if tuple(w.shape) != (D, pix.shape[1] * C):
+            raise ValueError(f"hier_tokenizer: level {l} weight {tuple(w.shape)}, expected {(D, pix.shape[1] * C)}")
+        a.pix[l], a.w[l], a.P[l] = pix.data_ptr(), w.data_ptr(), pix.shape[1]
+        a.b[l] = _need(b_list[l], _BF16, "hier_tokenizer b", 1).data_ptr() if b_list[l] is not None else None
+        flops += 2.0 * B * N * pix.shape[1] * C * D
+    y = None
+    if wf is not None:
+        _need(wf, _BF16, "hier_tokenizer wf", 2)
+        if tuple(wf.shape) != (E, E):
+            raise ValueError(f"hier_tokenizer: fusion weight {tuple(wf.shape)}, expected {(E, E)}")
+        a.wf = wf.data_ptr()
+        a.bf = _need(bf, _BF16, "hier_tokenizer bf", 1).data_ptr() if bf is not None else None
+        y = torch.empty((B, N, E), device=x.device, dtype=_BF16)
+        a.y = y.data_ptr()
+    h = torch.empty((B, N, E), device=x.device, dtype=_BF16)
+    a.h = h.data_ptr()
+    a.B, a.C, a.HW, a.N, a.L, a.D = B, C, H * W, N, L, D
+    check(_launch("hier_fwd_kernel", flops, lambda: lib.sfcvit_hier_tokenizer_fwd(ctypes.byref(a), _stream())),
+          "sfcvit_hier_tokenizer_fwd")
+    return y, h
+
+
 # ----------------------------------------------------------------------------
 # elementwise / loss / optimizer
 # ----------------------------------------------------------------------------

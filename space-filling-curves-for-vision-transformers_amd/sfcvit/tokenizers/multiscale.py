@@ -1,8 +1,10 @@
 """Hierarchical (multi-scale) curve tokenizers: several SFCEmbedding1D levels, resampled to a common
 length, concatenated on the feature axis and fused by a Linear
 (reference: src/tokenizers/multiscale/multi_hilbert.py:9-40, multi_morton.py:9-40; what the reference's
-main.py:269-274 instantiates).  Every level and the fusion run on the HIP kernels; the resampling
-(identity-sized in the reference's own configuration) and the concatenation are plain torch plumbing."""
+main.py:269-274 instantiates).  When every level has the same token count -- the reference's own configuration
+[16, 4, 1]: the resampling is then the identity -- the whole forward is ONE kernel (csrc/hier_tokenizer.hip: gather,
+level projections, concatenation in LDS, fusion GEMM).  Otherwise every level and the fusion run on their own HIP
+kernels with torch's interpolate / cat between them."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -34,7 +36,32 @@ class _Hierarchical(nn.Module):
     def _level(img_size, pre_patch_size, patch_size, in_channels, embed_dim, curve_fn):
         return SFCEmbedding1D(img_size, pre_patch_size, patch_size, in_channels, embed_dim, curve_fn)
 
-    def forward(self, x):
+    def _fusable(self, x):
+        """One common token count, a CUDA input and shapes inside the fused kernel's envelope (decided on the host)."""
+        if not x.is_cuda or len(set(self.patch_list)) != 1 or any(lv.n_patches != self.patch_list[0] for lv in self.levels):
+            return False
+        key = (x.shape[1],)
+        if getattr(self, "_fuse_key", None) != key:
+            from .. import ops
+            D = self.levels[0].embed_dim
+            ppt = [lv.input_dim // x.shape[1] for lv in self.levels]
+            ok = all(lv.embed_dim == D and lv.input_dim % x.shape[1] == 0 for lv in self.levels)
+            self._fuse_ok = ok and ops.hier_tokenizer_supported(len(self.levels), D, x.shape[1], ppt)
+            self._fuse_key = key
+        return self._fuse_ok
+
+    def forward(self, x, one_kernel=None):
+        if self._fusable(x):
+            img = self.levels[0]._geom[0]
+            if x.dim() != 4 or x.shape[2] != img or x.shape[3] != img:
+                raise ValueError(f"expected [B, C, {img}, {img}] input, got {tuple(x.shape)}")
+            return F.hier_tokenizer(x, [lv._pix_table(x.device) for lv in self.levels],
+                                    [lv.proj.weight for lv in self.levels], [lv.proj.bias for lv in self.levels],
+                                    self.fusion.weight, self.fusion.bias, one_kernel)
+        return self.forward_unfused(x)
+
+    def forward_unfused(self, x):
+        """Level kernels + torch interpolate / cat + fusion GEMM (any token counts)."""
         patches = [level(x) for level in self.levels]
         n_tokens = self.patch_list[0]
         for i in range(1, len(patches)):

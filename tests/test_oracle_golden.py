@@ -96,7 +96,7 @@ def test_model_against_reference_fixture(name, golden_dir):
                               atol=2e-4 * g["l2"] / max(1.0, mine.numel() ** 0.5) + 1e-9), k
 
 
-@pytest.mark.parametrize("name", ["hier_morton32", "hier_hilbert32_resample"])
+@pytest.mark.parametrize("name", ["hier_morton32", "hier_hilbert32_resample", "hier_morton32_d256", "hier_hilbert32_4lvl"])
 def test_hierarchical_tokenizer_against_reference_fixture(name, golden_dir):
     from oracle.cases import HIER_CASES
     img, cin, plist, dim, curve, batch = HIER_CASES[name]

@@ -116,9 +116,12 @@ def test_tokenizer_linearity_at_full_size():
         assert (pe(x).float() - ref).abs().max() <= 2e-2 * ref.abs().max()
 
 
-@pytest.mark.parametrize("name", ["hier_morton32", "hier_hilbert32_resample"])
-def test_hierarchical_tokenizer(name):
-    from oracle.cases import HIER_CASES
+@pytest.mark.parametrize("name", ["hier_morton32", "hier_hilbert32_resample", "hier_morton32_d256", "hier_hilbert32_4lvl"])
+def test_hierarchical_tokenizer(name, golden_dir):
+    """Hierarchical tokenizers against the oracle and the reference's fixture.  The last two cases are inside the fused
+    kernel's envelope (csrc/hier_tokenizer.hip: one kernel for gather + level projections + concat + fusion); the
+    first two take the composed path (level kernels, torch interpolate / cat, fusion GEMM)."""
+    from oracle.cases import HIER_CASES, HIER_FUSED_CASES
     from sfcvit.tokenizers import HierarchicalHilbertEmbedding, HierarchicalMortonEmbedding
     img, cin, plist, dim, curve, batch = HIER_CASES[name]
     cls = HierarchicalMortonEmbedding if curve == "z" else HierarchicalHilbertEmbedding
@@ -127,9 +130,60 @@ def test_hierarchical_tokenizer(name):
     mod.load_state_dict(sd)                                   # same keys as the reference module (fixture "keys")
     x = formula.image_batch(batch, cin, img, img)
     ref = vit_oracle.hierarchical_tokens(x, sd, img, plist, curve)
-    got = mod.to("cuda", dtype=torch.bfloat16)(x.cuda()).float().cpu()
+    mod = mod.to("cuda", dtype=torch.bfloat16)
+    assert mod._fusable(x.cuda()) == (name in HIER_FUSED_CASES)
+    got = mod(x.cuda()).float().cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max() <= 3e-2 * ref.abs().max()
+    with open(os.path.join(golden_dir, "hierarchical.json")) as f:
+        gold = json.load(f)[name]
+    gv = torch.stack([got.flatten()[i] for i in gold["idx"]])
+    assert (gv - torch.tensor(gold["val"])).abs().max() <= 3e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize("name,xdt,pdt", [("hier_morton32_d256", torch.float32, torch.bfloat16),
+                                          ("hier_hilbert32_4lvl", torch.float32, torch.float32),
+                                          ("hier_morton32_d256", torch.bfloat16, torch.bfloat16)])
+def test_fused_hierarchical_tokenizer_matches_composed_path_and_oracle_gradients(name, xdt, pdt):
+    """Both fused forms -- everything in one kernel, and gather + levels + concatenation in one kernel followed by the
+    fusion GEMM (the default) -- against the composed path on the same module: the level outputs are rounded to bf16 at
+    the same point, so the outputs differ by fp32 summation order only (<= 2 bf16 ulp of the largest value).  Gradients
+    of sum(y * r) w.r.t. every level weight / bias and the fusion weight / bias: fused vs composed (cosine >= 0.999)
+    and vs the oracle's autograd (cosine >= 0.99, norm 5 %).  Covers 3 levels x 256 (reference default), 4 levels x 64
+    with a ragged last row tile (48 rows), fp32 and bf16 images, fp32 and bf16 parameters."""
+    from oracle.cases import HIER_CASES
+    from sfcvit.tokenizers import HierarchicalHilbertEmbedding, HierarchicalMortonEmbedding
+    img, cin, plist, dim, curve, batch = HIER_CASES[name]
+    cls = HierarchicalMortonEmbedding if curve == "z" else HierarchicalHilbertEmbedding
+    sd = vit_oracle.hierarchical_state(img, cin, plist, dim, curve)
+    x = formula.image_batch(batch, cin, img, img)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    ref = vit_oracle.hierarchical_tokens(x, dict(sd, **leaves), img, plist, curve)
+    r = formula.wave("cotangent." + name, tuple(ref.shape))
+    (ref * r).sum().backward()
+
+    outs, grads = [], []
+    for mode in ("one_kernel", "levels_kernel+gemm", "composed"):
+        mod = cls(img, cin, plist, dim)
+        mod.load_state_dict(sd)
+        mod = mod.to("cuda", dtype=pdt)
+        xin = x.to("cuda", dtype=xdt)
+        assert mod._fusable(xin)
+        y = mod.forward_unfused(xin) if mode == "composed" else mod(xin, one_kernel=(mode == "one_kernel"))
+        (y.float() * r.cuda()).sum().backward()
+        outs.append(y.detach().float().cpu())
+        grads.append({k: p.grad.detach().float().cpu() for k, p in mod.named_parameters()})
+    scale = float(ref.detach().abs().max())
+    cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+    for o, gr in zip(outs[:2], grads[:2]):
+        assert (o - outs[2]).abs().max() <= 2 * 2.0 ** -8 * scale
+        assert (o - ref.detach()).abs().max() <= 3e-2 * scale
+        assert set(gr) == set(leaves)
+        for k in gr:
+            g, gc, go = gr[k].flatten(), grads[2][k].flatten(), leaves[k].grad.flatten()
+            assert cos(g, gc) >= 0.999, (k, cos(g, gc))
+            assert cos(g, go) >= 0.99, (k, cos(g, go))
+            assert abs(float(g.norm() / go.norm()) - 1.0) <= 5e-2, k
 
 
 def _tok_cases():
