@@ -322,6 +322,9 @@ int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s);
 // attention_wide.hip: head dims 128 / 192 / 256; return -1 for head dim 64.
 int attn_wide_fwd(const sfcvit_attn_args &a, hipStream_t s);
 int attn_wide_bwd(const sfcvit_attn_args &a, hipStream_t s);
+// attention_long.hip: forward with K / V of the whole sequence resident, head dim 64, 256 < N <= 608; -1 otherwise.
+int attn_long_fwd(const sfcvit_attn_args &a, hipStream_t s);
+int attn_long_bwd(const sfcvit_attn_args &a, hipStream_t s);
 
 }  // namespace sfcvit
 
@@ -331,6 +334,9 @@ extern "C" int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream) {
     if (int rc = check_args(a, "attention_fwd", false)) return rc;
     if (int rc = attn_wide_fwd(*a, static_cast<hipStream_t>(stream)); rc >= 0) return rc;
     if (int rc = attn_seq_fwd(*a, static_cast<hipStream_t>(stream)); rc >= 0) return rc;
+    const char *el = getenv("SFCVIT_ATTN_LONG");             // "0": tiled kernel for every N > 256 (A/B, tests); read per call
+    if (!(el && el[0] == '0'))
+        if (int rc = attn_long_fwd(*a, static_cast<hipStream_t>(stream)); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a);
     return check_launch("attention_fwd");
@@ -366,6 +372,9 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
     if (int rc = check_launch("attention_bwd delta")) return rc;
     if (int rc = attn_wide_bwd(*a, s); rc >= 0) return rc;
     if (int rc = attn_seq_bwd(*a, s); rc >= 0) return rc;
+    const char *el = getenv("SFCVIT_ATTN_LONG");             // "0": tiled kernels for every N > 256 (A/B, tests)
+    if (!(el && el[0] == '0'))
+        if (int rc = attn_long_bwd(*a, s); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
     hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(THREADS), 0, s, *a);
     if (int rc = check_launch("attention_bwd kv")) return rc;

@@ -555,6 +555,55 @@ def test_patch_embed_tiled_vs_generic_and_reference(ops, curve, img, D, B, xdt):
     assert torch.equal(tiled, ops.patch_embed_fwd(x, pix, w, b, desc))
 
 
+@pytest.mark.parametrize("B,N,H,p", [(2, 576, 2, 0.0), (1, 576, 3, 0.1), (2, 577, 1, 0.1), (1, 257, 2, 0.0), (2, 300, 1, 0.1),
+                                     (1, 600, 1, 0.0), (1, 608, 2, 0.1)])
+def test_attention_long_kernels_vs_tiled_and_reference(ops, B, N, H, p, monkeypatch):
+    """The sequence-resident kernels for 256 < N <= 608 (attention_long.hip: 12 waves per (batch, head); forward with
+    192-key softmax chunks, dK/dV with Q and dO resident, dQ with K and V resident) against the tiled kernels
+    (SFCVIT_ATTN_LONG=0) with the SAME dropout mask and against fp32 math with that mask; log-sum-exp against torch;
+    bit-reproducible.  Covers N = 576 (the compile-time forward instance), ragged N (257, 577), padding fragments
+    (300, 600) and the limit 608."""
+    g = torch.Generator(device="cuda").manual_seed(31)
+    D, seed = H * 64, 4242
+    qkv = torch.randn(B, N, 3 * D, device="cuda", generator=g)
+    qkv[0, 7, :64] *= 5                                   # one peaked row: the running max moves between key chunks
+    qkv[0, N - 3, D:D + 64] = qkv[0, 7, :64]
+    qkv = bf(qkv)
+    dout = bf(torch.randn(B, N, D, device="cuda", generator=g))
+    plain = bf(torch.randn(B, N, 3 * D, device="cuda", generator=g))
+    monkeypatch.setenv("SFCVIT_ATTN_LONG", "0")
+    o_t, l_t = ops.attention_fwd(qkv, H, p, seed)
+    o_pt, l_pt = ops.attention_fwd(plain, H, p, seed)
+    d_t = ops.attention_bwd(plain, o_pt, l_pt, dout, H, p, seed)
+    monkeypatch.setenv("SFCVIT_ATTN_LONG", "1")
+    o_l, l_l = ops.attention_fwd(qkv, H, p, seed)
+    o_2, l_2 = ops.attention_fwd(qkv, H, p, seed)
+    assert torch.equal(o_l, o_2) and torch.equal(l_l, l_2)
+    close(o_l, o_t.float())
+    assert torch.allclose(l_l, l_t, atol=2e-3, rtol=1e-4)
+    mask = ops.dropout_mask(B * H * N, N, p, seed).float().view(B, H, N, N) if p > 0 else 1.0
+    sp = lambda t: t.reshape(B, N, H, 64).transpose(1, 2)
+
+    def fp32(x):
+        xf = x.float().requires_grad_(True)
+        q, k, v = xf.split(D, dim=-1)
+        s = (sp(q) @ sp(k).transpose(-1, -2)) / 8.0
+        ref = ((torch.softmax(s, -1) * mask) @ sp(v)).transpose(1, 2).reshape(B, N, D)
+        ref.backward(dout.float())
+        return ref.detach(), torch.logsumexp(s.detach(), -1), xf.grad
+
+    ref, lse_ref, _ = fp32(qkv)
+    close(o_l, ref)
+    assert torch.allclose(l_l, lse_ref, atol=2e-2, rtol=1e-2)
+    # Backward on the un-spiked input: where P -> 1 the flash form dS = P (dP - delta) cancels (delta comes from the
+    # bf16-rounded O) and bf16-rounding-sized differences in O are amplified, in the tiled kernels as much as here.
+    o_p, l_p = ops.attention_fwd(plain, H, p, seed)
+    d_l = ops.attention_bwd(plain, o_p, l_p, dout, H, p, seed)
+    assert torch.equal(d_l, ops.attention_bwd(plain, o_p, l_p, dout, H, p, seed))
+    close(d_l, d_t.float(), rel=1 / 64, abs_scale=1 / 32)      # both round P and dS to bf16, in different association
+    close(d_l, fp32(plain)[2], rel=1 / 64, abs_scale=1 / 32)
+
+
 @pytest.mark.parametrize("B,N,H,p", [(3, 196, 2, 0.1), (2, 100, 3, 0.0), (2, 300, 1, 0.0)])
 def test_attention_bwd_column_sums(ops, B, N, H, p):
     """The in_proj bias gradient as a by-product of the attention backward: 192 sums per (batch, head) out of the one-pass

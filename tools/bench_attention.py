@@ -35,18 +35,24 @@ def timeit(fn, reps=20):
 fl = 4.0 * B * H * N * N * 64
 byt_f = B * N * 4 * H * 64 * 2
 byt_b = B * N * 8 * H * 64 * 2
-rows = {"fwd": [], "bwd fused": [], "bwd two-kernel": []}
+rows = {"fwd": [], "fwd tiled (SFCVIT_ATTN_LONG=0)": [], "bwd fused": [], "bwd two-kernel": [], "bwd two-kernel, tiled (SFCVIT_ATTN_LONG=0)": []}
 for rnd in range(5):
     rows["fwd"].append(timeit(lambda: ops.attention_fwd(qkv, H, p, 5)))
+    os.environ["SFCVIT_ATTN_LONG"] = "0"
+    rows["fwd tiled (SFCVIT_ATTN_LONG=0)"].append(timeit(lambda: ops.attention_fwd(qkv, H, p, 5)))
+    os.environ["SFCVIT_ATTN_LONG"] = "1"
     os.environ["SFCVIT_ATTN_BWD_FUSED"] = "1"
     rows["bwd fused"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
     os.environ["SFCVIT_ATTN_BWD_FUSED"] = "0"
     rows["bwd two-kernel"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
+    os.environ["SFCVIT_ATTN_LONG"] = "0"
+    rows["bwd two-kernel, tiled (SFCVIT_ATTN_LONG=0)"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
+    os.environ["SFCVIT_ATTN_LONG"] = "1"
 os.environ["SFCVIT_ATTN_BWD_FUSED"] = "1"
 print(f"B={B} N={N} H={H} hd=64 dropout={p}")
 for k, v in rows.items():
     v = sorted(v)
     med = v[len(v) // 2]
-    f, by = (fl, byt_f) if k == "fwd" else (2.5 * fl, byt_b)
-    print(f"{k:16s} median {med:7.1f} us  min {v[0]:7.1f}   {f / med / 1e6:7.1f} TFLOP/s   {by / med / 1e3:7.1f} GB/s algorithmic "
+    f, by = (fl, byt_f) if k.startswith("fwd") else (2.5 * fl, byt_b)
+    print(f"{k:44s} median {med:7.1f} us  min {v[0]:7.1f}   {f / med / 1e6:7.1f} TFLOP/s   {by / med / 1e3:7.1f} GB/s algorithmic "
           f"({by / med / 1e3 / 8000 * 100:4.1f} % of 8 TB/s)")
