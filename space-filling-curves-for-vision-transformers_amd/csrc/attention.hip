@@ -365,6 +365,17 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
             }
         }
     }
+    {   // sequence-resident kernels (hd = 64, 256 < N <= 608): delta comes out of their dQ kernel, the column sums too
+        const char *el = getenv("SFCVIT_ATTN_LONG");         // "0": tiled kernels for every N > 256 (A/B, tests)
+        if (!(el && el[0] == '0')) {
+            sfcvit_attn_args f = *a;
+            if (!a->colsum_out) f.colsum_part = nullptr;
+            if (int rc = attn_long_bwd(f, s); rc >= 0) {
+                if (rc || !a->colsum_out) return rc;
+                return launch_colsum_reduce(a->colsum_part, a->B, D3, a->colsum_out, a->colsum_bf16, stream);
+            }
+        }
+    }
     const int rc_rest = [&]() -> int {
     const int64_t groups = int64_t(a->B) * a->N * a->H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(unsigned((groups * 8 + THREADS - 1) / THREADS)), dim3(THREADS), 0, s,
@@ -372,9 +383,6 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
     if (int rc = check_launch("attention_bwd delta")) return rc;
     if (int rc = attn_wide_bwd(*a, s); rc >= 0) return rc;
     if (int rc = attn_seq_bwd(*a, s); rc >= 0) return rc;
-    const char *el = getenv("SFCVIT_ATTN_LONG");             // "0": tiled kernels for every N > 256 (A/B, tests)
-    if (!(el && el[0] == '0'))
-        if (int rc = attn_long_bwd(*a, s); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
     hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(THREADS), 0, s, *a);
     if (int rc = check_launch("attention_bwd kv")) return rc;

@@ -135,6 +135,35 @@ __global__ __launch_bounds__(LT) void attn_long_fwd_kernel(const sfcvit_attn_arg
     }
 }
 
+// Column sums of the workgroup's slice of dqkv (the in_proj bias gradient, sfcvit_attn_args.colsum_part).  A stored
+// fragment x[hf][r] (row = lane & 15, column 16 hf + 4 (lane >> 4) + r) is summed over its 16 rows with DPP (every lane
+// of a DPP row then holds all 16 sums of its 4-column group) and lane i keeps sum number i: ONE running register per
+// lane instead of 16 (the dK/dV kernel has no 32 registers to spare).  `valid` masks rows that are not stored.
+__device__ __forceinline__ void colsum_add(float &run, const f32x4 (&x)[4], bool valid, int lane) {
+#pragma unroll
+    for (int hf = 0; hf < 4; hf++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float v = row16_sum(valid ? x[hf][r] : 0.f);
+            if ((lane & 15) == 4 * hf + r) run += v;
+        }
+}
+// Waves are summed through LDS (the images are dead by now); 64 threads write the (batch, head) partial that
+// launch_colsum_reduce sums over the batch.  Fixed order throughout: bit-reproducible.
+__device__ __forceinline__ void wg_colsum(float run, char *smem, float *__restrict__ dst, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, i = lane & 15;
+    float *red = reinterpret_cast<float *>(smem);
+    __syncthreads();                                                  // every wave is done with the LDS images
+    red[wave * 64 + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3)] = run;
+    __syncthreads();
+    if (tid < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < LW; w++) t += red[w * 64 + tid];
+        dst[tid] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // backward, dK / dV: Q and dO of the whole (batch, head) resident (kc images, 2 x 72 KiB at N = 576) plus lse, delta and
 // the dropout row keys of every query (12 B per row); the 12 waves own 16-key fragments (3 each at N = 576) and walk all
@@ -174,6 +203,7 @@ __global__ __launch_bounds__(LT) void attn_long_bwd_kv_kernel(const sfcvit_attn_
     const float dsc = 1.f / (1.f - a.dropout_p);
     uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
 
+    float csk = 0.f, csv = 0.f;                                       // running column sums of this wave's dK / dV rows (colsum_add)
     for (int kfi = wave; kfi < nf; kfi += LW) {
         const int key = 16 * kfi + (lane & 15);
         bf16x8 kn[2], vn[2];                                          // the wave's next key fragment, in flight during this one
@@ -223,17 +253,28 @@ __global__ __launch_bounds__(LT) void attn_long_bwd_kv_kernel(const sfcvit_attn_
         mfma_fence();
         store_rows(dbase + D, ld, key, key < N, dk, 1.f, lane);
         store_rows(dbase + 2 * D, ld, key, key < N, dv, 1.f, lane);
+        if (a.colsum_part) {                                          // padding keys hold non-zero dV (p = exp2(-lse)): not stored, not summed
+            colsum_add(csk, dk, key < N, lane);
+            colsum_add(csv, dv, key < N, lane);
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             kf[kk] = kn[kk];
             vf[kk] = vn[kk];
         }
     }
+    if (a.colsum_part) {
+        float *part = a.colsum_part + size_t(b) * 3 * D + h * HD;
+        wg_colsum(csk, smem, part + D, tid);
+        wg_colsum(csv, smem, part + 2 * D, tid);
+    }
 }
 
 // ---------------------------------------------------------------------------
 // backward, dQ: K and V resident (both kc images); the 12 waves own 16-query fragments and walk all keys in 32-key chunks.
 // Same arithmetic as attn_seq_bwd_q_kernel; the sequence is padded to 32 keys, padding keys carry dS = 0.
+// Runs FIRST and also produces delta[b, h, q] = sum_d dO O for the dK/dV kernel: the dO fragment is in registers anyway,
+// the matching O fragment is two more 16-byte loads per lane -- no separate delta pass over O and dO (28 us per layer).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LT) void attn_long_bwd_q_kernel(const sfcvit_attn_args a, int npad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -243,17 +284,28 @@ __global__ __launch_bounds__(LT) void attn_long_bwd_q_kernel(const sfcvit_attn_a
     const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
     const uint16_t *qp = base, *kp = base + D, *vp = base + 2 * D;
     const uint16_t *dop = static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD;
-    const float *lse = a.lse + (size_t(b) * a.H + h) * N, *del = a.delta + (size_t(b) * a.H + h) * N;
-    bf16x8 qfr[2], dof[2];
-    float lse_q, del_q;
+    const uint16_t *op = static_cast<const uint16_t *>(a.out) + size_t(b) * N * D + h * HD;
+    const float *lse = a.lse + (size_t(b) * a.H + h) * N;
+    float *del = a.delta + (size_t(b) * a.H + h) * N;
+    // sum over the 64 head columns of dO * O for row (lane & 15): 16 products per lane, then over the 4 lane groups
+    auto row_delta = [&](const bf16x8 (&x)[2], const bf16x8 (&y)[2]) __attribute__((always_inline)) {
+        float t = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) t += bf2f(uint16_t(x[kk][e])) * bf2f(uint16_t(y[kk][e]));
+        return group_sum(t);
+    };
+    bf16x8 qfr[2], dof[2], ofr[2];
+    float lse_q;
     {
         const int qq = 16 * wave + (lane & 15);
         lse_q = qq < N ? lse[qq] * 1.4426950408889634f : 0.f;
-        del_q = qq < N ? del[qq] : 0.f;
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             qfr[kk] = global_frag(qp, ld, 16 * wave, N, kk, lane);
             dof[kk] = global_frag(dop, D, 16 * wave, N, kk, lane);
+            ofr[kk] = global_frag(op, D, 16 * wave, N, kk, lane);
         }
     }
     dma_long<false>(kimg, kp, ld, N, npad, tid);
@@ -268,15 +320,19 @@ __global__ __launch_bounds__(LT) void attn_long_bwd_q_kernel(const sfcvit_attn_a
     const uint32_t seed = eff_seed(a.dropout_seed, a.seed_off);
     uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
 
+    float csq = 0.f;                                                  // running column sums of this wave's dQ rows (colsum_add)
     for (int qf = wave; qf < nqf; qf += LW) {
         const int q = 16 * qf + (lane & 15), qn = q + 16 * LW;
-        bf16x8 qnx[2], donx[2];                                       // next fragment of this wave
-        const float lse_n = qn < N ? lse[qn] * 1.4426950408889634f : 0.f, del_n = qn < N ? del[qn] : 0.f;
+        bf16x8 qnx[2], donx[2], onx[2];                               // next fragment of this wave
+        const float lse_n = qn < N ? lse[qn] * 1.4426950408889634f : 0.f;
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             qnx[kk] = global_frag(qp, ld, 16 * (qf + LW), N, kk, lane);
             donx[kk] = global_frag(dop, D, 16 * (qf + LW), N, kk, lane);
+            onx[kk] = global_frag(op, D, 16 * (qf + LW), N, kk, lane);
         }
+        const float del_q = row_delta(dof, ofr);                      // rows >= N: zero fragments -> 0
+        if (q < N && lane < 16) del[q] = del_q;
         const uint32_t drk = drop_row_key(seed, (uint64_t(b) * a.H + h) * uint64_t(N) + uint64_t(q));
         f32x4 dq[4];
 #pragma unroll
@@ -308,30 +364,32 @@ __global__ __launch_bounds__(LT) void attn_long_bwd_q_kernel(const sfcvit_attn_a
         }
         mfma_fence();
         store_rows(dbase, ld, q, q < N, dq, 1.f, lane);
+        if (a.colsum_part) colsum_add(csq, dq, q < N, lane);
         lse_q = lse_n;
-        del_q = del_n;
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             qfr[kk] = qnx[kk];
             dof[kk] = donx[kk];
+            ofr[kk] = onx[kk];
         }
     }
+    if (a.colsum_part) wg_colsum(csq, smem, a.colsum_part + size_t(b) * 3 * D + h * HD, tid);
 }
 
 constexpr int LONG_MAX_LDS = 2 * ((LONG_MAX_N + 31) / 32 * 32) * 128 + 3 * ((LONG_MAX_N + 31) / 32 * 32) * 4;
 
 }  // namespace
 
-// -1: not eligible; else a status.  a.delta must hold delta[b, h, q] (attn_delta_kernel ran).
+// -1: not eligible; else a status.  a.delta is written here (dQ kernel) and read by the dK/dV kernel.
 int attn_long_bwd(const sfcvit_attn_args &a, hipStream_t s) {
     if (a.hd != HD || a.N <= 256 || a.N > LONG_MAX_N) return -1;
     const int npad = (a.N + 31) / 32 * 32;
     for (const void *k : {reinterpret_cast<const void *>(&attn_long_bwd_kv_kernel), reinterpret_cast<const void *>(&attn_long_bwd_q_kernel)})
         if (int rc = raise_lds_limit(k, LONG_MAX_LDS, "attention_long attribute")) return rc;
-    hipLaunchKernelGGL(attn_long_bwd_kv_kernel, dim3(a.H, a.B), dim3(LT), size_t(2 * npad * 128 + 3 * npad * 4), s, a, npad);
-    if (int rc = check_launch("attention_long_bwd kv")) return rc;
     hipLaunchKernelGGL(attn_long_bwd_q_kernel, dim3(a.H, a.B), dim3(LT), size_t(2 * npad * 128), s, a, npad);
-    return check_launch("attention_long_bwd q");
+    if (int rc = check_launch("attention_long_bwd q")) return rc;
+    hipLaunchKernelGGL(attn_long_bwd_kv_kernel, dim3(a.H, a.B), dim3(LT), size_t(2 * npad * 128 + 3 * npad * 4), s, a, npad);
+    return check_launch("attention_long_bwd kv");
 }
 
 // -1: not eligible (the caller takes the tiled kernel); else a status.

@@ -604,10 +604,11 @@ def test_attention_long_kernels_vs_tiled_and_reference(ops, B, N, H, p, monkeypa
     close(d_l, fp32(plain)[2], rel=1 / 64, abs_scale=1 / 32)
 
 
-@pytest.mark.parametrize("B,N,H,p", [(3, 196, 2, 0.1), (2, 100, 3, 0.0), (2, 300, 1, 0.0)])
+@pytest.mark.parametrize("B,N,H,p", [(3, 196, 2, 0.1), (2, 100, 3, 0.0), (2, 300, 1, 0.0), (2, 576, 2, 0.1), (1, 601, 1, 0.1), (2, 700, 1, 0.0)])
 def test_attention_bwd_column_sums(ops, B, N, H, p):
     """The in_proj bias gradient as a by-product of the attention backward: 192 sums per (batch, head) out of the one-pass
-    kernel (N <= 224) or a column-sum pass over dqkv (longer sequences) -- against the column sums of the dqkv the same
+    kernel (N <= 224), out of the sequence-resident dQ and dK/dV kernels (256 < N <= 608) or from a column-sum pass over
+    dqkv (other lengths: 300 -> long, 700 -> tiled + pass) -- against the column sums of the dqkv the same
     call returned (fp32 sums of the bf16-rounded values differ from the kernel's sums of the unrounded ones by rounding)."""
     g = torch.Generator(device="cuda").manual_seed(13)
     D = H * 64
