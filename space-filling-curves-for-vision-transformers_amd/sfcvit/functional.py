@@ -11,6 +11,8 @@ needs is local to one function:
 All activations and parameters are bf16 inside; fp32 parameters are cast on entry
 (differentiably), so gradients come back in the parameter's own dtype.
 """
+import math
+
 import torch
 from torch.autograd import Function
 
@@ -264,21 +266,43 @@ class _Attention(Function):
     columns h*hd.. of each third): the core of nn.MultiheadAttention and of altvit.Attention (altvit.py:131-142)."""
 
     @staticmethod
-    def forward(ctx, qkv, n_heads):
+    def forward(ctx, qkv, n_heads, scale):
         qkv = _c(qkv)
-        out, lse = ops.attention_fwd(qkv, n_heads)
+        out, lse = ops.attention_fwd(qkv, n_heads, scale=scale)
         ctx.save_for_backward(qkv, out, lse)
-        ctx.n_heads = n_heads
+        ctx.n_heads, ctx.scale = n_heads, scale
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
-        return ops.attention_bwd(qkv, out, lse, _c(dout), ctx.n_heads), None
+        return ops.attention_bwd(qkv, out, lse, _c(dout), ctx.n_heads, scale=ctx.scale), None, None
+
+
+def _head_padding(D, n_heads):
+    """(head dim, kernel head dim) of a model width / head count; equal when the kernels have that head dim."""
+    if D % n_heads:
+        raise ValueError(f"attention: width {D} is not a multiple of n_heads = {n_heads}")
+    hd = D // n_heads
+    hp = ops.padded_head_dim(hd)
+    if hp is None:
+        raise ValueError(f"attention: head dim {hd} (= {D} / {n_heads}) exceeds the largest supported one, "
+                         f"{max(ops.SUPPORTED_HEAD_DIMS)}")
+    return hd, hp
 
 
 def attention(qkv, n_heads):
-    return _Attention.apply(_bf(qkv), n_heads)
+    """Head dims the kernels do not have (32, 48, 96, ...) run zero-padded to the next one that exists: the padded
+    q / k / v columns add nothing to q k^T or p v, the softmax scale stays 1 / sqrt(head dim)."""
+    qkv = _bf(qkv)
+    D = qkv.shape[-1] // 3
+    hd, hp = _head_padding(D, n_heads)
+    if hp == hd:
+        return _Attention.apply(qkv, n_heads, None)
+    lead = qkv.shape[:-1]
+    padded = torch.nn.functional.pad(qkv.reshape(*lead, 3, n_heads, hd), (0, hp - hd)).reshape(*lead, 3 * n_heads * hp)
+    out = _Attention.apply(padded, n_heads, 1.0 / math.sqrt(hd))
+    return out.reshape(*lead, n_heads, hp)[..., :hd].reshape(*lead, D)
 
 
 def _fast_gemm_shape(M, N, K):
@@ -333,20 +357,21 @@ class _EncoderLayer(Function):
     identity.  Masks are functions of (seed, element index), regenerated in backward."""
 
     @staticmethod
-    def forward(ctx, x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps, p, seeds):
+    def forward(ctx, x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps, p, seeds, scale):
         B, N, D = x.shape
+        Da = in_w.shape[0] // 3                             # attention width: D, or n_heads * padded head dim (encoder_layer)
         sa, s1_, sf, s2_ = seeds
         x2 = _c(x).view(B * N, D)
         qkv = ops.gemm(x2, in_w, bias=in_b)
-        o, lse = ops.attention_fwd(qkv.view(B, N, 3 * D), n_heads, p, sa)
-        s1 = ops.gemm(o.view(B * N, D), out_w, bias=out_b, residual=x2, dropout_p=p, dropout_seed=s1_)
+        o, lse = ops.attention_fwd(qkv.view(B, N, 3 * Da), n_heads, p, sa, scale=scale)
+        s1 = ops.gemm(o.view(B * N, Da), out_w, bias=out_b, residual=x2, dropout_p=p, dropout_seed=s1_)
         x1, mean1, rstd1 = ops.layernorm_fwd(s1, n1_w, n1_b, eps)
         h = ops.gemm(x1, w1, bias=b1, act=ops.ACT_RELU, dropout_p=p, dropout_seed=sf)
         s2 = ops.gemm(h, w2, bias=b2, residual=x1, dropout_p=p, dropout_seed=s2_)
         y, mean2, rstd2 = ops.layernorm_fwd(s2, n2_w, n2_b, eps)
         ctx.save_for_backward(x2, qkv, o, lse, s1, mean1, rstd1, x1, h, s2, mean2, rstd2,
                               in_w, out_w, n1_w, w1, w2, n2_w)
-        ctx.n_heads, ctx.shape, ctx.p, ctx.seeds = n_heads, (B, N, D), p, seeds
+        ctx.n_heads, ctx.shape, ctx.p, ctx.seeds, ctx.scale = n_heads, (B, N, D), p, seeds, scale
         ctx.small = (in_b, out_b, n1_b, b1, b2, n2_b)      # parameters only needed for their gradient slots
         return y.view(B, N, D)
 
@@ -390,29 +415,44 @@ class _EncoderLayer(Function):
         dw1 = wg(dh, x1, w1)
         dx1 = ops.gemm_dx(dh, w1, residual=ds2)
         ds1, dg1, dbt1, da, dbo = ln_bwd(dx1, s1, mean1, rstd1, n1_w, n1_b, out_b, s1_)
-        o2 = o.view(B * N, D)
+        Da = in_w.shape[0] // 3
+        o2 = o.view(B * N, Da)
         dwo = wg(da, o2, out_w)
         do = ops.gemm_dx(da, out_w)
         # the in_proj bias gradient (column sums of dqkv) comes out of the attention backward itself
         bi_slot = _slot(in_b)
-        dqkv, dbi = ops.attention_bwd(qkv.view(B, N, 3 * D), o, lse, do.view(B, N, D), ctx.n_heads, p, sa,
-                                      colsum=bi_slot if bi_slot is not None else True)
-        dqkv = dqkv.view(B * N, 3 * D)
+        dqkv, dbi = ops.attention_bwd(qkv.view(B, N, 3 * Da), o, lse, do.view(B, N, Da), ctx.n_heads, p, sa,
+                                      colsum=bi_slot if bi_slot is not None else True, scale=ctx.scale)
+        dqkv = dqkv.view(B * N, 3 * Da)
         if bi_slot is None:
             dbi = dbi.to(_BF16)
         dwi = wg(dqkv, x2, in_w)
         dx = ops.gemm_dx(dqkv, in_w, residual=ds1)
         if ss:
             ss.join(dw2, dw1, dwo, dwi)
-        return (dx.view(B, N, D), dwi, dbi, dwo, dbo, dg1, dbt1, dw1, db1, dw2, db2, dg2, dbt2, None, None, None, None)
+        return (dx.view(B, N, D), dwi, dbi, dwo, dbo, dg1, dbt1, dw1, db1, dw2, db2, dg2, dbt2, None, None, None, None, None)
 
 
 def encoder_layer(x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b, n_heads, eps=1e-5,
                   dropout_p=0.0):
-    """dropout_p > 0 = training-mode nn.TransformerEncoderLayer (fresh masks every call)."""
+    """dropout_p > 0 = training-mode nn.TransformerEncoderLayer (fresh masks every call).
+    A head dim the attention kernels do not have (embed_dim / n_heads = 32, 48, 96, ...) runs on the next one that
+    exists: in_proj's rows and out_proj's columns are zero-padded per head (differentiable torch plumbing on the
+    weights, 3 D^2 elements -- not on the activations), so q, k, v come out of the projection GEMM already padded, the
+    padded columns add nothing to q k^T or p v, and out_proj ignores them; the softmax scale stays 1 / sqrt(head dim)."""
     args = [_bf(t) for t in (x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w, n2_b)]
+    D = args[0].shape[-1]
+    hd, hp = _head_padding(D, n_heads)
+    scale = None
+    if hp != hd:
+        pad = torch.nn.functional.pad
+        args[1] = pad(args[1].reshape(3, n_heads, hd, D), (0, 0, 0, hp - hd)).reshape(3 * n_heads * hp, D)
+        if args[2] is not None:
+            args[2] = pad(args[2].reshape(3, n_heads, hd), (0, hp - hd)).reshape(3 * n_heads * hp)
+        args[3] = pad(args[3].reshape(D, n_heads, hd), (0, hp - hd)).reshape(D, n_heads * hp)
+        scale = 1.0 / math.sqrt(hd)
     seeds = tuple(ops.next_seed() for _ in range(4)) if dropout_p > 0 else (0, 0, 0, 0)
-    return _EncoderLayer.apply(*args, n_heads, eps, float(dropout_p), seeds)
+    return _EncoderLayer.apply(*args, n_heads, eps, float(dropout_p), seeds, scale)
 
 
 # ----------------------------------------------------------------------------

@@ -329,8 +329,17 @@ def _attn_dims(D3, n_heads):
     return D, hd
 
 
-def attention_fwd(qkv, n_heads, dropout_p=0.0, dropout_seed=0):
-    """qkv [B, N, 3*D] bf16 -> out [B, N, D] bf16, lse [B, H, N] fp32."""
+def padded_head_dim(hd):
+    """The kernel head dim a model head dim runs on: itself when supported, else the next supported one (zero-padded
+    q / k / v columns change neither q k^T nor p v; the softmax scale stays 1 / sqrt(hd)); None above the largest."""
+    for s in sorted(SUPPORTED_HEAD_DIMS):
+        if hd <= s:
+            return s
+    return None
+
+
+def attention_fwd(qkv, n_heads, dropout_p=0.0, dropout_seed=0, scale=None):
+    """qkv [B, N, 3*D] bf16 -> out [B, N, D] bf16, lse [B, H, N] fp32.  scale: softmax scale, default 1 / sqrt(head dim)."""
     _need(qkv, _BF16, "attention qkv", 3)
     B, N, D3 = qkv.shape
     D, hd = _attn_dims(D3, n_heads)
@@ -338,7 +347,7 @@ def attention_fwd(qkv, n_heads, dropout_p=0.0, dropout_seed=0):
     lse = torch.empty((B, n_heads, N), device=qkv.device, dtype=torch.float32)
     a = _lib.AttnArgs()
     a.qkv, a.out, a.lse = qkv.data_ptr(), out.data_ptr(), lse.data_ptr()
-    a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
+    a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, (1.0 / math.sqrt(hd) if scale is None else float(scale))
     a.dropout_p, a.dropout_seed = dropout_p, dropout_seed
     if dropout_p > 0.0 and STEP_STATE is not None:
         a.seed_off = STEP_STATE.data_ptr()
@@ -347,7 +356,7 @@ def attention_fwd(qkv, n_heads, dropout_p=0.0, dropout_seed=0):
     return out, lse
 
 
-def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0, colsum=None):
+def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0, colsum=None, scale=None):
     """-> dqkv [, column sums of dqkv over all B * N rows = the in_proj bias gradient: colsum=True -> fp32 [3D] (new
     tensor), or a bf16 [3D] tensor to write into (e.g. a slot of the flat gradient buffer)]."""
     _need(dout, _BF16, "attention dout", 3)
@@ -358,7 +367,7 @@ def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0, c
     a = _lib.AttnArgs()
     a.qkv, a.out, a.lse, a.dout = qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr()
     a.dqkv, a.delta = dqkv.data_ptr(), delta.data_ptr()
-    a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, 1.0 / math.sqrt(hd)
+    a.B, a.N, a.H, a.hd, a.scale = B, N, n_heads, hd, (1.0 / math.sqrt(hd) if scale is None else float(scale))
     a.dropout_p, a.dropout_seed = dropout_p, dropout_seed
     if dropout_p > 0.0 and STEP_STATE is not None:
         a.seed_off = STEP_STATE.data_ptr()

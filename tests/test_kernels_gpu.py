@@ -439,6 +439,62 @@ def test_attention_wide_heads_dropout_and_limits(ops):
         ops.attention_fwd(bf(torch.randn(1, 576, 3 * 128, device="cuda")), 1)
 
 
+@pytest.mark.parametrize("D,H,p", [(128, 4, 0.0), (192, 4, 0.0), (96, 1, 0.0), (128, 4, 0.1)])
+def test_encoder_layer_with_head_dims_the_kernels_do_not_have(D, H, p):
+    """embed_dim / n_heads = 32, 48, 96: constructor-compatible reference models (nn.TransformerEncoderLayer takes any
+    divisor) run on the next head dim the attention kernels have, through zero-padded in_proj rows / out_proj columns and
+    the true 1 / sqrt(head dim) softmax scale.  Against torch's own layer in fp32 on the same bf16-rounded weights:
+    output and every parameter gradient (dropout 0); with dropout only finiteness and run-to-run mask freshness."""
+    from sfcvit import functional as F
+    torch.manual_seed(3)
+    B, N, Fd = 3, 50, 2 * D
+    ref = torch.nn.TransformerEncoderLayer(D, H, Fd, dropout=0.0, batch_first=True).cuda()
+    with torch.no_grad():
+        for q in ref.parameters():
+            q.copy_(q.bfloat16().float())
+    names = ["self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias",
+             "norm1.weight", "norm1.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+             "norm2.weight", "norm2.bias"]
+    sd = dict(ref.named_parameters())
+    mine = [sd[n].detach().clone().requires_grad_(True) for n in names]
+    x = bf(torch.randn(B, N, D, device="cuda")).float()
+    r = torch.randn(B, N, D, device="cuda")
+    xr = x.clone().requires_grad_(True)
+    (ref(xr) * r).sum().backward()
+    xm = x.clone().requires_grad_(True)
+    y = F.encoder_layer(xm, *mine, H, dropout_p=p)
+    assert y.shape == (B, N, D) and torch.isfinite(y.float()).all()
+    if p > 0:
+        assert not torch.equal(y, F.encoder_layer(xm, *mine, H, dropout_p=p))
+        return
+    close(y, ref(x).detach(), rel=1 / 64, abs_scale=1 / 32)
+    (y.float() * r).sum().backward()
+    for n, t, tr in [("x", xm, xr)] + [(n, t, sd[n]) for n, t in zip(names, mine)]:
+        g, gr = t.grad.flatten(), tr.grad.flatten()
+        cos = float(torch.dot(g, gr) / (g.norm() * gr.norm() + 1e-30))
+        assert cos >= 0.995, (n, cos)
+        assert abs(float(g.norm() / gr.norm()) - 1) <= 3e-2, n
+
+
+def test_attention_op_with_padded_head_dim():
+    """functional.attention on a packed projection with head dim 48: zero-padded to 64 inside, true softmax scale."""
+    from sfcvit import functional as F
+    g = torch.Generator(device="cuda").manual_seed(8)
+    B, N, H, hd = 2, 70, 3, 48
+    qkv = bf(torch.randn(B, N, 3 * H * hd, device="cuda", generator=g))
+    dout = torch.randn(B, N, H * hd, device="cuda", generator=g)
+    qf = qkv.float().requires_grad_(True)
+    q, k, v = qf.split(H * hd, dim=-1)
+    sp = lambda t: t.reshape(B, N, H, hd).transpose(1, 2)
+    ref = (torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(hd), -1) @ sp(v)).transpose(1, 2).reshape(B, N, H * hd)
+    ref.backward(dout)
+    qm = qkv.clone().requires_grad_(True)
+    out = F.attention(qm, H)
+    close(out, ref.detach())
+    out.backward(bf(dout))
+    close(qm.grad, qf.grad, rel=1 / 48, abs_scale=1 / 24)
+
+
 @pytest.mark.parametrize("M,N,K", [(896, 512, 256), (1024, 768, 384), (200, 136, 64)])
 def test_gemm_fused_column_sums(ops, M, N, K):
     """colsum= : column sums of the epilogue's result next to C (bias gradient of the previous Linear).  Fused into
