@@ -203,6 +203,14 @@ typedef struct sfcvit_gemm_args {
     int32_t colsum_bf16;
     const uint32_t *seed_off; /* NULL, or a device word added to dropout_seed when the kernel RUNS (sfcvit_step_advance):
                                  lets a captured graph draw a new mask per replay */
+    void *actmask;         /* NULL, or a bit matrix [M][ld_actmask bytes], bit (n & 7) of byte n >> 3 of row m <-> C[m, n] > 0:
+                              with act = RELU it is WRITTEN (fused into the persistent kernel's epilogue, a separate pass
+                              over C otherwise); with dact = RELU it MAY be read in place of aux_in (the persistent kernel
+                              does: 2 bytes instead of 32 per lane and row; aux_in must be valid all the same).
+                              linear2's dX through ReLU + dropout needs only the sign pattern of the stored activation
+                              (torch:nn/modules/transformer.py:980-982): 19 MB instead of 308 MB per ViT-B layer.
+                              N % 16 == 0, ld_actmask even and >= N / 8, 2-byte aligned. */
+    int32_t ld_actmask;
 } sfcvit_gemm_args;
 
 int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);

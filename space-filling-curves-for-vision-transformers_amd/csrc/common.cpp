@@ -10,6 +10,7 @@ thread_local int g_gemm[5] = {0, 0, 0, 0, 0};
 }
 
 bool gemm_fused_colsum() { return g_gemm[0] == 1 && (g_gemm[2] & 16); }
+bool gemm_fused_actmask() { return g_gemm[0] == 1 && (g_gemm[2] & 32); }
 
 void note_gemm_kernel(int family, int a, int b, int c, int d) {
     g_gemm[0] = family; g_gemm[1] = a; g_gemm[2] = b; g_gemm[3] = c; g_gemm[4] = d;

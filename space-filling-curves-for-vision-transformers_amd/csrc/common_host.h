@@ -20,6 +20,7 @@ int raise_lds_limit(const void *kernel, int bytes, const char *what);
 // rocprofv3 shows): family 1 gemm8p_kernel<a, b>, 2 gemm8p_km_kernel, 3 gemm256_kernel<a, b, c, d>, 4 gemm_kernel<a, b, c>.
 void note_gemm_kernel(int family, int a = 0, int b = 0, int c = 0, int d = 0);
 bool gemm_fused_colsum();     // the kernel noted last was the 8-phase kernel with column sums in its epilogue
+bool gemm_fused_actmask();    // ... with the activation bit mask written (act) or read (dact) by its epilogue
 
 // rowwise.hip: out[n] = sum over `nparts` rows of part[nparts][N] in a fixed order; out fp32 or bf16.
 int launch_colsum_reduce(const float *part, int nparts, int N, void *out, int out_bf16, void *stream);

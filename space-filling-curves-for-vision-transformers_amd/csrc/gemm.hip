@@ -92,6 +92,20 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(const sfcvit_gemm_args
     epilogue_tile<4, 4, HEAVY>(g, acc, reinterpret_cast<float *>(smem) + wave * (32 * 68), m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+// actmask fallback (kernels without the fused form): bit (n & 7) of byte n >> 3 of row m = C[m, n] > 0; 16 columns per thread.
+__global__ __launch_bounds__(256) void relu_bits_kernel(const uint16_t *__restrict__ c, int ldc, int M, int N,
+                                                       uint8_t *__restrict__ mask, int ldm) {
+    const int64_t v = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int nv = N >> 4;
+    if (v >= int64_t(M) * nv) return;
+    const int m = int(v / nv), n = int(v % nv) * 16;
+    const uint16_t *p = c + size_t(m) * ldc + n;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) bits |= uint32_t(bf2f(p[r]) > 0.f) << r;
+    *reinterpret_cast<uint16_t *>(mask + size_t(m) * ldm + (n >> 3)) = uint16_t(bits);
+}
+
 // C[m, n] = sum_z slab[z][m][n]; 4 columns per thread.
 __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ ws, int splits, int M, int N, void *c,
                                                     int ldc, int c_is_f32) {
@@ -139,7 +153,20 @@ extern "C" int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream) {
         if (!a->workspace || a->workspace_bytes < sfcvit_gemm_colsum_workspace(a->M, a->N) || !aligned16(a->workspace))
             return fail(SFCVIT_EINVAL, "gemm: colsum_out needs sfcvit_gemm_colsum_workspace(M, N) bytes of workspace");
     }
+    if (a && a->actmask) {
+        if (a->N % 16 || a->ld_actmask % 2 || a->ld_actmask * 8 < a->N || (reinterpret_cast<uintptr_t>(a->actmask) & 1))
+            return fail(SFCVIT_EINVAL, "gemm: actmask needs N %% 16 == 0, an even ld_actmask >= N / 8 and 2-byte alignment");
+        if (a->act != SFCVIT_ACT_RELU && a->dact != SFCVIT_ACT_RELU)
+            return fail(SFCVIT_EINVAL, "gemm: actmask goes with act = RELU (written) or dact = RELU (read)");
+        if (a->c_is_f32 || a->splitk > 1) return fail(SFCVIT_EINVAL, "gemm: actmask not with fp32 C or split-K");
+    }
     if (int rc = gemm_impl(a, stream)) return rc;
+    if (a->actmask && a->act == SFCVIT_ACT_RELU && !gemm_fused_actmask()) {      // the kernel that ran does not write the bits
+        const int64_t nv = int64_t(a->M) * (a->N / 16);
+        hipLaunchKernelGGL(relu_bits_kernel, dim3(unsigned((nv + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const uint16_t *>(a->c), a->ldc, a->M, a->N, static_cast<uint8_t *>(a->actmask), a->ld_actmask);
+        if (int rc = check_launch("gemm actmask pass")) return rc;
+    }
     if (a->colsum_out && !gemm_fused_colsum())   // the kernel that ran had no fused column sums: one pass over the stored C
         return sfcvit_colsum(a->c, a->M, a->N, a->ldc, a->colsum_out, a->colsum_bf16, a->workspace, a->workspace_bytes, stream);
     return SFCVIT_OK;

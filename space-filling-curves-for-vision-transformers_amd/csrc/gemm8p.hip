@@ -58,7 +58,7 @@ constexpr int T = 512, HALF = 16384, KTB = 65536, LDS_BYTES = 2 * KTB;
 // gemm8p_kernel's LDS beyond the ring: the 4-entry tile ring, one [16][128 B] store patch per wave, the bias vector
 constexpr int LDS_TQ = LDS_BYTES, LDS_PATCH = LDS_TQ + 64, LDS_BIAS = LDS_PATCH + 8 * 2048, LDS_MAX = 160 * 1024;
 constexpr int BIAS_MAX_N = (LDS_MAX - LDS_BIAS) / 2;
-enum { RELU = 1, DROP = 2, RES = 4, DACT = 8, CSUM = 16 };
+enum { RELU = 1, DROP = 2, RES = 4, DACT = 8, CSUM = 16, BITS = 32 };   // BITS: sfcvit_gemm_args.actmask written (RELU) / read (DACT)
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -123,12 +123,25 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] += rv[r];
     }
-    if (MASK & DACT) {
-        float a[16];
-        unpack8f(side[0], a);
-        unpack8f(side[1], a + 8);
+    if ((MASK & BITS) && (MASK & RELU)) {                       // the sign pattern of what is stored (no RES with RELU: dispatcher)
+        uint32_t bits = 0;
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = a[r] > 0.f ? v[r] * dact_scale : 0.f;
+        for (int r = 0; r < 16; r++) bits |= uint32_t(v[r] > 0.f) << r;
+        uint8_t *mp = static_cast<uint8_t *>(g.actmask) + size_t(m) * g.ld_actmask + (n >> 3);
+        asm volatile("global_store_short %0, %1, off\n\ts_nop 1" ::"v"(mp), "v"(bits) : "memory");
+    }
+    if (MASK & DACT) {
+        if (MASK & BITS) {                                      // side[0][0] = the 16 mask bits of this row segment
+            const uint32_t bits = side[0][0];
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = (bits >> r & 1u) ? v[r] * dact_scale : 0.f;
+        } else {
+            float a[16];
+            unpack8f(side[0], a);
+            unpack8f(side[1], a + 8);
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = a[r] > 0.f ? v[r] * dact_scale : 0.f;
+        }
     }
     uint16_t *c = static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n;
     // In the fragment layout a store instruction touches 64 different 64-byte segments (16 rows per quarter-wave,
@@ -385,7 +398,12 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         auto batch = [&](auto i0c, auto i1c) __attribute__((always_inline)) {
             constexpr int i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
             u32x4 side[i1 - i0][2];
-            if (MASK & (RES | DACT)) {
+            if ((MASK & DACT) && (MASK & BITS)) {
+#pragma unroll
+                for (int i = i0; i < i1; i++)
+                    side[i - i0][0][0] = *reinterpret_cast<const uint16_t *>(static_cast<const uint8_t *>(g.actmask) +
+                                                                             size_t(m0 + 16 * i) * g.ld_actmask + (n0 >> 3));
+            } else if (MASK & (RES | DACT)) {
 #pragma unroll
                 for (int i = i0; i < i1; i++) {
                     const uint16_t *p = sp + size_t(m0 + 16 * i) * ld_side + n0;
@@ -452,7 +470,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     // through with these halves by then), which at a tile boundary is before the epilogue: everything the first
     // k-tile of the next tile waits for is older than the stores, and its wait can leave them outstanding --
     // vmcnt(4 + NSTORE).  The next wait is a whole k-tile later.
-    constexpr int NSTORE = 2 * NI + ((MASK & CSUM) ? 4 : 0);  // store instructions per wave and epilogue
+    constexpr int NSTORE = 2 * NI + ((MASK & CSUM) ? 4 : 0) + (((MASK & BITS) && (MASK & RELU)) ? NI : 0);  // store instructions per wave and epilogue
     auto stage_next = [&](int buf) __attribute__((always_inline)) {
         stage_a(ca, buf, 1);
         advance(ca, true);
@@ -774,6 +792,10 @@ int launch_mask(const sfcvit_gemm_args &a, int mask, int grid, hipStream_t s) {
     case RELU | DROP: return launch<NI, RELU | DROP>(a, grid, s);
     case DACT: return launch<NI, DACT>(a, grid, s);
     case DACT | CSUM: return launch<NI, DACT | CSUM>(a, grid, s);
+    case RELU | BITS: return launch<NI, RELU | BITS>(a, grid, s);
+    case RELU | DROP | BITS: return launch<NI, RELU | DROP | BITS>(a, grid, s);
+    case DACT | BITS: return launch<NI, DACT | BITS>(a, grid, s);
+    case DACT | CSUM | BITS: return launch<NI, DACT | CSUM | BITS>(a, grid, s);
     default: return -1;
     }
 }
@@ -822,6 +844,7 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     if (a.residual) mask |= RES;
     if (a.dact == SFCVIT_ACT_RELU) mask |= DACT;
     if (a.colsum_out) mask |= CSUM;                          // built with DACT only; other combinations fall back
+    if (a.actmask && (mask & (RELU | DACT)) && !(mask & RES)) mask |= BITS;   // with RELU + RES the bits come from the pass over C
     if ((mask & DACT) && a.bias) return -1;                  // the DACT variants leave the bias out (register room)
     if (a.bias && a.N > BIAS_MAX_N) return -1;               // the bias vector lives in LDS
     const int cus = device_cus() / 8 * 8;

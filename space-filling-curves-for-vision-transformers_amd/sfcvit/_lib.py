@@ -38,7 +38,8 @@ class GemmArgs(ctypes.Structure):
                 ("c_is_f32", c_int32), ("splitk", c_int32), ("workspace", c_void_p),
                 ("workspace_bytes", c_int64), ("force_generic", c_int32),
                 ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("dact_scale", c_float),
-                ("row_offset", c_int32), ("colsum_out", c_void_p), ("colsum_bf16", c_int32), ("seed_off", c_void_p)]
+                ("row_offset", c_int32), ("colsum_out", c_void_p), ("colsum_bf16", c_int32), ("seed_off", c_void_p),
+                ("actmask", c_void_p), ("ld_actmask", c_int32)]
 
 
 class AttnArgs(ctypes.Structure):

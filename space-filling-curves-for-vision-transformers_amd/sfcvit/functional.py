@@ -89,6 +89,7 @@ class _SideStream:
 
 import os as _os
 SIDE_STREAM_WGRAD = _os.environ.get("SFCVIT_SIDE_STREAM", "0") == "1"
+USE_ACTMASK = _os.environ.get("SFCVIT_ACTMASK", "1") == "1"        # "0": linear2's dX reads the stored activation (A/B)
 
 
 def _bgrad(dy2, b=None):
@@ -366,9 +367,14 @@ class _EncoderLayer(Function):
         o, lse = ops.attention_fwd(qkv.view(B, N, 3 * Da), n_heads, p, sa, scale=scale)
         s1 = ops.gemm(o.view(B * N, Da), out_w, bias=out_b, residual=x2, dropout_p=p, dropout_seed=s1_)
         x1, mean1, rstd1 = ops.layernorm_fwd(s1, n1_w, n1_b, eps)
-        h = ops.gemm(x1, w1, bias=b1, act=ops.ACT_RELU, dropout_p=p, dropout_seed=sf)
+        # The dX GEMM through ReLU + dropout needs only the sign pattern of h: a bit matrix written by linear1's epilogue
+        # (19 MB instead of 308 MB per ViT-B layer read back in backward; sfcvit_gemm_args.actmask)
+        hbits = (torch.empty((B * N, w1.shape[0] // 8), device=x.device, dtype=torch.uint8)
+                 if USE_ACTMASK and w1.shape[0] % 16 == 0 else None)
+        h = ops.gemm(x1, w1, bias=b1, act=ops.ACT_RELU, dropout_p=p, dropout_seed=sf, actmask=hbits)
         s2 = ops.gemm(h, w2, bias=b2, residual=x1, dropout_p=p, dropout_seed=s2_)
         y, mean2, rstd2 = ops.layernorm_fwd(s2, n2_w, n2_b, eps)
+        ctx.hbits = hbits
         ctx.save_for_backward(x2, qkv, o, lse, s1, mean1, rstd1, x1, h, s2, mean2, rstd2,
                               in_w, out_w, n1_w, w1, w2, n2_w)
         ctx.n_heads, ctx.shape, ctx.p, ctx.seeds, ctx.scale = n_heads, (B, N, D), p, seeds, scale
@@ -409,7 +415,7 @@ class _EncoderLayer(Function):
         # ... and the bias gradient of linear1 is the column sum of dh: fused into that GEMM's epilogue
         b1_slot = _slot(b1)
         dh, db1 = ops.gemm_dx(df, w2, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p),
-                              colsum=b1_slot if b1_slot is not None else True)
+                              colsum=b1_slot if b1_slot is not None else True, actmask=ctx.hbits)
         if b1_slot is None:
             db1 = db1.to(_BF16)
         dw1 = wg(dh, x1, w1)

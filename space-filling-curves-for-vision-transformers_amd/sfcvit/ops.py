@@ -165,10 +165,12 @@ def next_seed():
 
 def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, residual=None,
          aux_in=None, dact=ACT_NONE, want_aux=False, out_f32=False, splitk=None, force_generic=False,
-         dropout_p=0.0, dropout_seed=0, dact_scale=1.0, out=None, row_offset=0, colsum=None):
+         dropout_p=0.0, dropout_seed=0, dact_scale=1.0, out=None, row_offset=0, colsum=None, actmask=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  a: [M,K] (or [K,M] if a_kmajor),
     b: [N,K] (or [K,N] if b_kmajor), bf16.  Returns C (and the pre-activation if want_aux; and the column sums of C
-    if `colsum` is True (fp32 [N]) or a bf16 [N] tensor to write them into, e.g. a bias-gradient slot)."""
+    if `colsum` is True (fp32 [N]) or a bf16 [N] tensor to write them into, e.g. a bias-gradient slot).
+    actmask: uint8 [M, N/8] bit matrix (bit n & 7 of byte n >> 3 <-> C[m, n] > 0): written with act = RELU, optionally
+    read in place of aux_in with dact = RELU (sfcvit_gemm_args.actmask)."""
     _rows2d(a, _BF16, "gemm a")
     _rows2d(b, _BF16, "gemm b")
     M, K = (a.shape[1], a.shape[0]) if a_kmajor else (a.shape[0], a.shape[1])
@@ -203,6 +205,11 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
     if dropout_p > 0.0 and STEP_STATE is not None:
         args.seed_off = STEP_STATE.data_ptr()
     args.row_offset = row_offset
+    if actmask is not None:
+        if actmask.dtype != torch.uint8 or actmask.dim() != 2 or actmask.shape[0] != M or actmask.shape[1] * 8 < N \
+                or actmask.stride(1) != 1 or actmask.device != a.device:
+            raise ValueError(f"gemm actmask: expected uint8 [{M}, >= {N // 8}] on {a.device}, got {actmask.dtype} {tuple(actmask.shape)}")
+        args.actmask, args.ld_actmask = actmask.data_ptr(), actmask.stride(0)
     plain = (bias is None and residual is None and aux_in is None and not want_aux and act == 0 and dact == 0
              and dropout_p == 0.0)
     if splitk is None:

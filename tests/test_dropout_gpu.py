@@ -122,7 +122,7 @@ def test_encoder_layer_training_mode_against_masked_reference(ops):
     dy = bf(r(B, N, D))
     order = ["in_w", "in_b", "out_w", "out_b", "n1_w", "n1_b", "w1", "b1", "w2", "b2", "n2_w", "n2_b"]
     leaves = [x.clone().requires_grad_(True)] + [P[k].clone().requires_grad_(True) for k in order]
-    y = F._EncoderLayer.apply(*leaves, H, 1e-5, p, seeds)
+    y = F._EncoderLayer.apply(*leaves, H, 1e-5, p, seeds, None)        # scale None = 1 / sqrt(head dim)
     y.backward(dy)
 
     # fp32 reference with the same masks

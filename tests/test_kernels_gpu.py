@@ -495,6 +495,38 @@ def test_attention_op_with_padded_head_dim():
     close(qm.grad, qf.grad, rel=1 / 48, abs_scale=1 / 24)
 
 
+@pytest.mark.parametrize("M,N,K,p", [(896, 512, 256, 0.1), (1792, 768, 256, 0.0), (448, 256, 384, 0.1), (200, 144, 64, 0.1)])
+def test_gemm_activation_bit_mask(ops, M, N, K, p):
+    """sfcvit_gemm_args.actmask: the sign pattern of a ReLU (+ dropout) output as a bit matrix, written by the forward GEMM
+    (fused into the persistent kernel's epilogue for the first three shapes, a pass over C for the last) and read by the
+    dX GEMM in place of the activation itself -- bits == (C > 0) exactly, C unchanged by asking for them, and the
+    gradient GEMM bit-identical with and without the mask (with and without fused column sums)."""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K))
+    b = bf(torch.randn(N, device="cuda", generator=g))
+    kw = dict(bias=b, act=ops.ACT_RELU, dropout_p=p, dropout_seed=41)
+    h0 = ops.gemm(x, w, **kw)
+    bits = torch.full((M, N // 8 + 2), 0xAB, device="cuda", dtype=torch.uint8)[:, : N // 8 + 2]
+    h = ops.gemm(x, w, actmask=bits, **kw)
+    assert torch.equal(h, h0)
+    want = (h.float() > 0).view(M, N // 8, 8).to(torch.int32)
+    packed = (want << torch.arange(8, device="cuda", dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits[:, : N // 8], packed)
+    assert (bits[:, N // 8:] == 0xAB).all()                          # nothing written beyond N / 8 bytes per row
+    dy = bf(torch.randn(M, K, device="cuda", generator=g))
+    w2 = bf(torch.randn(K, N, device="cuda", generator=g) / math.sqrt(K))      # linear2: [out = K, in = N]
+    for cs in (None, True):
+        ref = ops.gemm_dx(dy, w2, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p), colsum=cs)
+        got = ops.gemm_dx(dy, w2, aux_in=h, dact=ops.ACT_RELU, dact_scale=1.0 / (1.0 - p), colsum=cs, actmask=bits)
+        if cs:
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        else:
+            assert torch.equal(got, ref)
+    with pytest.raises(Exception, match="actmask"):
+        ops.gemm(x, w, bias=b, actmask=bits)                          # neither act nor dact is RELU
+
+
 @pytest.mark.parametrize("M,N,K", [(896, 512, 256), (1024, 768, 384), (200, 136, 64)])
 def test_gemm_fused_column_sums(ops, M, N, K):
     """colsum= : column sums of the epilogue's result next to C (bias gradient of the previous Linear).  Fused into
