@@ -245,7 +245,7 @@ def main():
         from sfcvit.training import GraphedTrainStep
         if world > 1:
             raise SystemExit("--graph: single-GPU only (the collectives are launched from autograd hooks)")
-        step = GraphedTrainStep(model, images, targets, opt, warmup=max(2, args.warmup))
+        step = GraphedTrainStep(model, images, targets, opt, warmup=max(2, args.warmup), preserve_state=False)   # its warm-up steps ARE the warm-up
 
     for _ in range(args.warmup):
         loss = step()

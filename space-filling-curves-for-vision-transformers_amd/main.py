@@ -22,7 +22,7 @@ import torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from sfcvit.models.vit import VisionTransformer1D                                  # noqa: E402
 import sfcvit.tokenizers as T                                                       # noqa: E402
-from sfcvit.training import FusedAdamW, GradReducer, SoftTargetCrossEntropy, WarmupCosine   # noqa: E402
+from sfcvit.training import FusedAdamW, GradReducer, GraphedTrainStep, SoftTargetCrossEntropy, WarmupCosine   # noqa: E402
 from sfcvit.training.loops import evaluate, train_with_mixup_or_cutmix             # noqa: E402
 
 
@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--resume-model-only", action="store_true",
                     help="take only the weights from --resume (e.g. a checkpoint the REFERENCE's main.py wrote: its "
                          "optimizer / scheduler states are torch.optim formats, see INTEGRATION.md)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay every training step from one hipGraph (the reference's torch.compile(model, "
+                         "mode='reduce-overhead'), main.py:284, for the whole step); single process")
     a = ap.parse_args()
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
@@ -132,10 +135,18 @@ def main():
             optimizer.lr = scheduler.lr_at(scheduler.n)
     os.makedirs(a.checkpoint_dir, exist_ok=True)
     ckpt = os.path.join(a.checkpoint_dir, f"checkpoint_{a.tokenizer}.pt")
+    graphed = None
+    if a.graph:
+        if world > 1:
+            raise SystemExit("--graph captures one process's step; the data-parallel reducer launches its collectives from "
+                             "autograd hooks and is not captured")
+        model.train()
+        graphed = GraphedTrainStep(model, torch.zeros(per_rank, 3, a.img_size, a.img_size, device=device),
+                                   torch.zeros(per_rank, a.classes, device=device), optimizer, scheduler)
 
     for epoch in range(start_epoch, a.epochs):
         tr_loss, tr_acc = train_with_mixup_or_cutmix(model, train_loader, train_criterion, optimizer, scheduler,
-                                                     device, reducer=reducer)
+                                                     device, reducer=reducer, graphed=graphed)
         te_loss, te_acc = evaluate(model, test_loader, test_criterion, device)
         if world > 1:                                  # equal shards per rank: the global figures are the rank means
             t = torch.tensor([tr_loss, tr_acc, te_loss, te_acc], device=device, dtype=torch.float64)

@@ -75,8 +75,12 @@ def train_with_scheduler(model, train_loader, criterion, optimizer, scheduler, d
 
 
 def train_with_mixup_or_cutmix(model, train_loader, criterion, optimizer, scheduler, device,
-                               mixup_alpha=0.2, cutmix_alpha=1.0, mix_prob=0.5, reducer=None):
-    """train.py:133-178.  `optimizer` is a FusedAdamW (clip inside) or any torch optimizer."""
+                               mixup_alpha=0.2, cutmix_alpha=1.0, mix_prob=0.5, reducer=None, graphed=None):
+    """train.py:133-178.  `optimizer` is a FusedAdamW (clip inside) or any torch optimizer.
+    graphed: a sfcvit.training.GraphedTrainStep built on this model / optimizer / scheduler with static buffers of the
+    loader's batch shape -- the step (forward, soft-target CE, backward, clip, AdamW, scheduler) is then one hipGraph
+    replay per batch (what main.py:284's torch.compile(mode="reduce-overhead") is after); batches of another size run
+    eagerly."""
     model.train()
     total_loss = torch.zeros((), device=device)
     total_correct = torch.zeros((), device=device)
@@ -87,6 +91,17 @@ def train_with_mixup_or_cutmix(model, train_loader, criterion, optimizer, schedu
             images, y_a, y_b, lam = mixup_data(images, labels, alpha=mixup_alpha)
         else:
             images, y_a, y_b, lam = cutmix_data(images, labels, alpha=cutmix_alpha)
+        if graphed is not None and images.shape == graphed.images.shape:
+            num_classes = graphed.targets.size(1)
+            graphed.images.copy_(images)
+            graphed.targets.copy_(lam * TF.one_hot(y_a, num_classes).float() + (1 - lam) * TF.one_hot(y_b, num_classes).float())
+            loss = graphed()
+            outputs = graphed.logits
+            preds = outputs.argmax(dim=1)
+            total_correct += (lam * (preds == y_a).float() + (1 - lam) * (preds == y_b).float()).sum()
+            total_loss += loss.float() * images.size(0)
+            total_samples += images.size(0)
+            continue
         optimizer.zero_grad()
         if reducer is not None:
             reducer.begin_step()

@@ -185,6 +185,8 @@ class FusedAdamW(FlatGradBuffer):
         if self.master.numel() != sd["master"].numel():
             raise ValueError("optimizer state does not fit these parameters")
         self.step_count, self.lr = sd["step"], sd["lr"]
+        if self.dev_state is not None:
+            self.dev_state[1] = self.step_count          # device-state mode: the kernel-side step counter follows
         self.master.copy_(sd["master"])
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])

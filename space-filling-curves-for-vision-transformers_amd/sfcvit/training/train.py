@@ -28,14 +28,20 @@ class GraphedTrainStep:
     step.  ~700 launches per ViT-B step (430 for ViT-Tiny) cost 7-11 ms of Python + ctypes per step when issued one
     by one; a replay is one call.
 
-    `images` / `targets` are STATIC buffers: copy each new batch into them (`.copy_`) before calling.  Needs the
+    `images` / `targets` are STATIC buffers: copy each new batch into them (`.copy_`) before calling; `.logits` is the
+    static output of the last replay (accuracy bookkeeping of the epoch loops).  Needs the
     optimizer's device-resident step state (dropout seeds and Adam's step count would otherwise be frozen into the
     graph as by-value kernel arguments); single process, no gradient reducer (its collectives are launched from
-    autograd hooks on another stream).  Shapes, model mode (train / eval) and dropout rates are fixed at capture."""
+    autograd hooks on another stream).  Shapes, model mode (train / eval) and dropout rates are fixed at capture.
+    The warm-up steps before the capture are real optimisation steps on whatever the static buffers hold; with
+    `preserve_state` (default) parameters, optimizer moments, step count and scheduler position are put back
+    afterwards, so that a training script that switches to the graphed step trains exactly as before."""
 
-    def __init__(self, model, images, targets, optimizer, scheduler=None, warmup=3):
+    def __init__(self, model, images, targets, optimizer, scheduler=None, warmup=3, preserve_state=True):
         self.model, self.images, self.targets, self.opt, self.sched = model, images, targets, optimizer, scheduler
+        self.logits = None
         optimizer.use_device_state(images.device)
+        snap = self._snapshot() if preserve_state else None
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -44,14 +50,47 @@ class GraphedTrainStep:
                 self._step()
                 self._after()
         cur.wait_stream(side)
+        if snap is not None:
+            self._restore(snap)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):            # records, does not run: device state and host mirror stay as they are
             self.loss = self._step()
 
-    def _step(self):
+    def _step(self):                                  # train_step() below, keeping the logits
         self.opt.advance()
-        return train_step(self.model, self.images, self.targets, self.opt)
+        self.opt.zero_grad()
+        logits = self.model(self.images)
+        loss = F.soft_target_cross_entropy(logits, self.targets)
+        loss.backward()
+        self.opt.step()
+        self.logits = logits.detach()
+        return loss.detach()
+
+    def _snapshot(self):
+        o = self.opt
+        sched = None if self.sched is None else {k: v for k, v in vars(self.sched).items() if isinstance(v, (int, float))}
+        return {"params": [p.detach().clone() for p in o.params], "step": o.step_count, "lr": o.lr, "sched": sched,
+                "moments": None if o.master is None else (o.master.clone(), o.m.clone(), o.v.clone())}
+
+    @torch.no_grad()
+    def _restore(self, s):
+        o = self.opt
+        for p, q in zip(o.params, s["params"]):       # parameters are views of the flat buffer by now: this restores it
+            p.copy_(q)
+        if s["moments"] is not None:
+            for dst, src in zip((o.master, o.m, o.v), s["moments"]):
+                dst.copy_(src)
+        else:                                         # the optimizer was built by the warm-up: back to a fresh one
+            o.master.copy_(o.flat_param.float())
+            o.m.zero_()
+            o.v.zero_()
+        o.step_count = s["step"]
+        o.dev_state[1] = s["step"]
+        if self.sched is not None:
+            for k, v in s["sched"].items():
+                setattr(self.sched, k, v)
+        o.lr = s["lr"]
 
     def _after(self):
         self.opt.step_count += 1                      # host mirror of the device counter (checkpoints read it)

@@ -537,7 +537,7 @@ def test_graphed_train_step_replays_bit_exactly_and_draws_new_masks():
             eager.append(float(train_step(model_e, x, tgt, opt_e)))
         model_g, opt_g = fresh()
         opt_g.use_device_state(seed_base=4242)
-        step = GraphedTrainStep(model_g, x.clone(), tgt.clone(), opt_g, warmup=2)      # 2 eager steps, then capture
+        step = GraphedTrainStep(model_g, x.clone(), tgt.clone(), opt_g, warmup=2, preserve_state=False)   # 2 eager steps that count, then capture
         graphed = [float(step()) for _ in range(4)]
         assert graphed == eager[2:], (graphed, eager)
         assert opt_g.step_count == 6 and int(opt_g.dev_state[1]) == 6
@@ -551,6 +551,53 @@ def test_graphed_train_step_replays_bit_exactly_and_draws_new_masks():
         assert not torch.equal(a, b)
     finally:
         ops.STEP_STATE = None
+
+
+def test_graphed_epoch_loop_trains_like_the_eager_loop_and_leaves_state_untouched_by_its_warm_up():
+    """train_with_mixup_or_cutmix(graphed=GraphedTrainStep(...)), main.py --graph: (a) building the graphed step (three
+    warm-up steps on the static buffers + capture) leaves parameters, Adam moments, step count and scheduler position
+    exactly as they were; (b) an epoch through the graph gives the same loss / accuracy and the same final weights, bit
+    for bit, as the eager loop in device-state mode from the same state with the same host RNG (dropout on)."""
+    import numpy as np
+    from sfcvit import ops
+    from sfcvit.training import FusedAdamW, GraphedTrainStep, SoftTargetCrossEntropy, WarmupCosine
+    from sfcvit.training.loops import train_with_mixup_or_cutmix
+    cfg, _ = MODEL_CASES["hilbert32_1d"]
+    g = torch.Generator().manual_seed(0)
+    xs, ys = torch.randn(3, 8, 3, 32, 32, generator=g), torch.randint(0, cfg.num_classes, (3, 8), generator=g)
+
+    class Loader(list):
+        dataset = range(24)
+
+    def epoch(graph):
+        m = build_model(cfg)
+        load_formula(m, cfg)
+        m = m.to("cuda", dtype=torch.bfloat16).train()
+        o = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=5e-5)
+        sch = WarmupCosine(o, 2, 20)
+        o.use_device_state(torch.device("cuda"), seed_base=99)
+        before = [p.detach().clone() for p in m.parameters()]
+        gs = None
+        if graph:
+            gs = GraphedTrainStep(m, torch.zeros(8, 3, 32, 32, device="cuda"), torch.zeros(8, cfg.num_classes, device="cuda"), o, sch)
+            assert all(torch.equal(a, b) for a, b in zip(before, m.parameters()))
+            assert o.step_count == 0 and int(o.dev_state[1]) == 0 and sch.n == 0 and not o.m.any() and not o.v.any()
+            assert torch.equal(o.master, o.flat_param.float()) and o.lr == sch.lr_at(0)
+        else:                                                          # eager, device-state mode: advance() opens every step
+            real = o.zero_grad
+            o.zero_grad = lambda *a_, **k_: (o.advance(), real(*a_, **k_))[1]
+        torch.manual_seed(11)
+        np.random.seed(11)
+        out = train_with_mixup_or_cutmix(m, Loader(zip(xs, ys)), SoftTargetCrossEntropy(), o, sch, "cuda", graphed=gs)
+        return out, [p.detach().float().clone() for p in m.parameters()], o.master.clone()
+
+    try:
+        (l_e, a_e), p_e, w_e = epoch(False)
+        (l_g, a_g), p_g, w_g = epoch(True)
+    finally:
+        ops.STEP_STATE = None
+    assert l_g == l_e and a_g == a_e
+    assert all(torch.equal(a, b) for a, b in zip(p_e, p_g)) and torch.equal(w_e, w_g)
 
 
 def test_torch_compile_reduce_overhead_runs_and_matches_eager():
