@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="replay the whole training step from one hipGraph")
     args = ap.parse_args()
+    if os.environ.get("SFCVIT_BENCH_WATCHDOG"):          # seconds: dump every thread's Python stack to stderr if still running then
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SFCVIT_BENCH_WATCHDOG"]), repeat=True)
 
     if args.cpu_only:
         wl = args.workload or "vit_tiny16_32_raster"

@@ -15,8 +15,19 @@ gradients per step, i.e. ~0.4-2.5 ms on the wire against >= 20 ms of backward, s
 few large buckets (default 32 MB: the last one, which cannot overlap with anything, costs ~0.2 ms) keep per-collective latency negligible and every
 link busy.
 """
+import os
+import sys
+import time
+
 import torch
 import torch.distributed as dist
+
+_DEBUG = os.environ.get("SFCVIT_DDP_DEBUG", "0") == "1"      # one stderr line per collective launched / waited for
+
+
+def _dbg(msg):
+    if _DEBUG:
+        print(f"[ddp r{dist.get_rank() if dist.is_initialized() else 0} {time.time() % 1000:8.3f}] {msg}", file=sys.stderr, flush=True)
 
 
 class GradReducer:
@@ -68,7 +79,9 @@ class GradReducer:
         if self.world > 1:
             # replicas must start identical: rank 0's parameters win (same-seed construction already gives that; a
             # model built or loaded differently on some rank would otherwise drift silently)
+            _dbg("broadcast parameters")
             dist.broadcast(self.opt.flat_param, src=0, group=self.group)
+            _dbg("broadcast done")
             master = getattr(self.opt, "master", None)
             if master is not None:
                 master.copy_(self.opt.flat_param)
@@ -91,6 +104,7 @@ class GradReducer:
         if self.world == 1:
             return
         s, e = self.buckets[b]
+        _dbg(f"launch bucket {b} [{s}:{e}] (#{len(self._handles)} of this step)")
         self._handles.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM,
                                              group=self.group, async_op=True))
 
@@ -114,8 +128,10 @@ class GradReducer:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for h in self._handles:
+        for i, h in enumerate(self._handles):
+            _dbg(f"wait #{i}")
             h.wait()
+        _dbg("step reduced")
         if timed:
             e1.record()
             self._wait_events.append((e0, e1))
