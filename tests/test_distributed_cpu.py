@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size 2, gloo.  GradReducer + FlatGradBuffer are device-agnostic torch
+"""The N>1 path on CPU: world sizes 2 and 4, gloo.  GradReducer + FlatGradBuffer are device-agnostic torch
 plumbing (the HIP step is not involved), so the bucketed, hook-driven all-reduce is exercised here with
 a small fp32 model: the reduced flat gradient must equal the average of the per-rank gradients, over two
 steps (first step = synchronous reduce after the flat layout is built, later steps = hooks)."""
@@ -62,26 +62,27 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_bucketed_allreduce_world2(tmp_path):
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_allreduce(tmp_path, world):
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got = torch.load(out)
     assert len(got["buckets"]) > 1
     assert got["buckets"][0][0] == 0 and got["buckets"][-1][1] == got["n"]
     for (s0, e0), (s1, e1) in zip(got["buckets"], got["buckets"][1:]):
         assert e0 == s1                                  # contiguous cover of the flat buffer
-    # single-process expectation: average over the two ranks' batches
+    # single-process expectation: average over the ranks' batches
     for step in range(3):
         model, _ = _model()
         ref = None
-        for rank in range(2):
+        for rank in range(world):
             model.zero_grad()
             x, y = _batch(rank, step)
             ((model(x) - y) ** 2).mean().backward()
             flat = torch.cat([torch.nn.functional.pad(p.grad.flatten(), (0, (-p.numel()) % 8)) for p in model.parameters()])
             ref = flat if ref is None else ref + flat
-        ref = ref / 2
+        ref = ref / world
         assert torch.allclose(got["grads"][step], ref, atol=1e-6), step
 
 
