@@ -333,3 +333,21 @@ def test_tile_descriptors_decline_other_tokenizers():
     pix = _pixel_table(curve_table(hilbert_curve, 32), 64, 2, 64)
     got = lib.sfcvit_tile_descriptors(ctypes.c_void_p(pix.ctypes.data), pix.shape[0], 256, 64, ctypes.c_void_p(desc.ctypes.data), desc.size)
     assert got >= 0          # a 16 x 16 tile in a different pixel order is still a tile; anything else is declined (0)
+
+
+def test_hier_tokenizer_envelope_and_padded_head_dims():
+    """Host-side decisions that pick kernels: the fused hierarchical tokenizer's envelope (sfcvit_hier_tokenizer_supported)
+    and the head dim a model head dim runs on (ops.padded_head_dim)."""
+    from sfcvit import ops
+    ok = ops.hier_tokenizer_supported
+    assert ok(3, 256, 3, [16, 16, 16])                 # main.py:269-274: [16, 4, 1] at 32 x 32 -> 16 pixels per token, 3 x 256
+    assert ok(4, 64, 3, [64, 64, 64, 64])              # 4 levels of 192 features
+    assert ok(1, 256, 3, [256])
+    assert not ok(3, 64, 3, [16, 16, 16])              # L * D = 192 is not a multiple of 256
+    assert not ok(2, 96, 3, [16, 16])                  # D % 64
+    assert not ok(2, 128, 3, [4, 4])                   # 12 features: not a multiple of 8
+    assert not ok(5, 256, 3, [16] * 5)                 # more than 4 levels
+    assert not ok(4, 256, 3, [256] * 4)                # 64 rows of (1024 + 4 x 768) bf16 exceed the LDS
+    assert not ok(2, 128, 3, [16])                     # one entry per level
+    assert [ops.padded_head_dim(h) for h in (16, 32, 48, 64, 96, 128, 160, 192, 200, 256)] == [64, 64, 64, 64, 128, 128, 192, 192, 256, 256]
+    assert ops.padded_head_dim(257) is None
