@@ -12,7 +12,8 @@
 //   * forward: one workgroup = 128 token rows (all of one class; rows = (token, image) pairs) x 256 output columns;
 //     per k-tile (64 features = 4 tile rows of one channel) every thread loads ONE 16-pixel row segment (64 B fp32 /
 //     32 B bf16, 16-byte vector loads: whole segments, fully used cache lines), converts it to bf16 and writes it into
-//     the swizzled LDS tile; W' streams through an LDS-DMA double buffer; 16x16x32 bf16 MFMA, fp32 accumulate; the
+//     the swizzled LDS tile; W' streams through a register-staged double buffer (LDS-DMA into a ring of three k-tiles
+//     was measured: 174 vs 168 us, no gain -- the bound is what the CUs can take in, not how); 16x16x32 bf16 MFMA, fp32 accumulate; the
 //     bias is added and the rows are stored straight to out[b, n, :].  The three column tiles of a row tile run
 //     back to back on one XCD, so the image is fetched from HBM once and re-read from that XCD's L2.
 //   * the per-pixel table of the generic kernel (patch_embed.hip: 8 scalar 2-byte loads per LDS vector, every
