@@ -291,6 +291,9 @@ int64_t sfcvit_attention_colsum_workspace(int B, int N, int H, int hd);
 
 int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream);
 int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream);
+/* HOST: name of the main kernel the calling thread's last sfcvit_attention_fwd / _bwd launched, as rocprofv3 prints it
+ * (e.g. "attn_seq_bwd_fused_kernel<13, true>"): tests assert through it that a shape ran on the production kernel. */
+int sfcvit_last_attn_kernel(char *buf, int n);
 
 /* ------------------------------------------------------------------------
  * Elementwise / loss / optimizer

@@ -90,6 +90,7 @@ ALTVIT_CASES = {
 #   vit_tiny_hilbert32   config 2: ViT-Tiny/16 @32, 192 / 3 heads / 12 layers / mlp 768, Hilbert, batch 256
 #   vit_tiny_raster32    config 1: the raster model of the CPU plumbing case, batch 32
 #   vit_b_hilbert224     config 3/4: ViT-B/16 @224, 768 / 12 / 12 / 3072, 1000 classes, Hilbert
+#   vit_b_hilbert224_b64 the same model at batch 64 (fixture holds 40 sampled logit columns: "logit_cols")
 #   vit_l_{z,hilbert,raster}384  config 5: ViT-L/16 @384 widths (1024 / 16 heads / mlp 4096, N = 576, 1000 classes),
 #                        depth 2 of the 24 layers (a 24-layer fp32 CPU pass is minutes; the layers are identical code)
 FULL_CASES = {
@@ -99,6 +100,10 @@ FULL_CASES = {
                                        num_classes=10, variant="1d"), 32),
     "vit_b_hilbert224": (OracleConfig("hilbert1d", 224, 256, 3, 768, depth=12, n_heads=12, mlp_dim=3072,
                                       num_classes=1000, variant="1d"), 2),
+    # the smallest ViT-B batch whose M = 64 * 196 = 12 544 = 56 * 224 = 49 * 256 rows take the production dispatch both ways
+    # (gemm8p_kernel<7, *> forward, the per-step transposed weight for dX): the kernels bench.py times (VERDICT r2 #1b)
+    "vit_b_hilbert224_b64": (OracleConfig("hilbert1d", 224, 256, 3, 768, depth=12, n_heads=12, mlp_dim=3072,
+                                          num_classes=1000, variant="1d"), 64),
     "vit_l_z384": (OracleConfig("morton1d", 384, 256, 3, 1024, depth=2, n_heads=16, mlp_dim=4096,
                                 num_classes=1000, variant="1d"), 2),
     "vit_l_hilbert384": (OracleConfig("hilbert1d", 384, 256, 3, 1024, depth=2, n_heads=16, mlp_dim=4096,

@@ -338,6 +338,7 @@ extern "C" int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream) {
     if (!(el && el[0] == '0'))
         if (int rc = attn_long_fwd(*a, static_cast<hipStream_t>(stream)); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
+    note_attn_kernel("attn_fwd_kernel");
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a);
     return check_launch("attention_fwd");
 }
@@ -384,6 +385,7 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
     if (int rc = attn_wide_bwd(*a, s); rc >= 0) return rc;
     if (int rc = attn_seq_bwd(*a, s); rc >= 0) return rc;
     dim3 grid((a->N + BLK - 1) / BLK, a->H, a->B);
+    note_attn_kernel("attn_bwd_kv_kernel");
     hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(THREADS), 0, s, *a);
     if (int rc = check_launch("attention_bwd kv")) return rc;
     hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(THREADS), 0, s, *a);

@@ -342,6 +342,7 @@ int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s) {
     const size_t lds = size_t(std::max(npad * FUSED_ROW_BYTES, FUSED_POST_BYTES)) + FUSED_EXTRA;
     const bool nf13 = (a.N + 15) / 16 == 13, drop = a.dropout_p > 0.f;
     const dim3 grid(a.H, a.B), block(FT);
+    note_attn_kernel("attn_seq_bwd_fused_kernel<%d, %s>", nf13 ? 13 : 0, drop ? "true" : "false");
     if (nf13 && drop) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<13, true>), grid, block, lds, s, a, npad);
     else if (nf13) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<13, false>), grid, block, lds, s, a, npad);
     else if (drop) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<0, true>), grid, block, lds, s, a, npad);

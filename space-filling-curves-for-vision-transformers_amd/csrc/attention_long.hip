@@ -386,6 +386,7 @@ int attn_long_bwd(const sfcvit_attn_args &a, hipStream_t s) {
     const int npad = (a.N + 31) / 32 * 32;
     for (const void *k : {reinterpret_cast<const void *>(&attn_long_bwd_kv_kernel), reinterpret_cast<const void *>(&attn_long_bwd_q_kernel)})
         if (int rc = raise_lds_limit(k, LONG_MAX_LDS, "attention_long attribute")) return rc;
+    note_attn_kernel("attn_long_bwd_kv_kernel");
     hipLaunchKernelGGL(attn_long_bwd_q_kernel, dim3(a.H, a.B), dim3(LT), size_t(2 * npad * 128), s, a, npad);
     if (int rc = check_launch("attention_long_bwd q")) return rc;
     hipLaunchKernelGGL(attn_long_bwd_kv_kernel, dim3(a.H, a.B), dim3(LT), size_t(2 * npad * 128 + 3 * npad * 4), s, a, npad);
@@ -399,6 +400,7 @@ int attn_long_fwd(const sfcvit_attn_args &a, hipStream_t s) {
     const int lds = 2 * npad * 128;
     for (const void *k : {reinterpret_cast<const void *>(&attn_long_fwd_kernel<0>), reinterpret_cast<const void *>(&attn_long_fwd_kernel<36>)})
         if (int rc = raise_lds_limit(k, 2 * ((LONG_MAX_N + 31) / 32 * 32) * 128, "attention_long attribute")) return rc;
+    note_attn_kernel("attn_long_fwd_kernel<%d>", npad == 576 ? 36 : 0);
     if (npad == 576) hipLaunchKernelGGL(attn_long_fwd_kernel<36>, dim3(a.H, a.B), dim3(LT), lds, s, a, npad);
     else hipLaunchKernelGGL(attn_long_fwd_kernel<0>, dim3(a.H, a.B), dim3(LT), lds, s, a, npad);
     return check_launch("attention_long_fwd");

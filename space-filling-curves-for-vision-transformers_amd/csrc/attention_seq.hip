@@ -344,6 +344,7 @@ int attn_seq_fwd(const sfcvit_attn_args &a, hipStream_t s) {
     if (a.N > SEQ_MAX_N) return -1;
     if (int rc = set_lds_limit()) return rc;
     const int npad = (a.N + 15) / 16 * 16;
+    note_attn_kernel("attn_seq_fwd_kernel<%d>", (a.N + 15) / 16 == 13 ? 13 : 0);
     if ((a.N + 15) / 16 == 13) hipLaunchKernelGGL(attn_seq_fwd_kernel<13>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128), s, a, npad);
     else hipLaunchKernelGGL(attn_seq_fwd_kernel<0>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128), s, a, npad);
     return check_launch("attention_seq_fwd");
@@ -354,6 +355,7 @@ int attn_seq_bwd(const sfcvit_attn_args &a, hipStream_t s) {
     if (int rc = set_lds_limit()) return rc;
     const int npad = (a.N + 31) / 32 * 32;
     const bool nf13 = (a.N + 15) / 16 == 13;
+    note_attn_kernel("attn_seq_bwd_kv_kernel<%d>", nf13 ? 13 : 0);
     if (nf13) hipLaunchKernelGGL(attn_seq_bwd_kv_kernel<13>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128 + 3 * npad * 4), s, a, npad);
     else hipLaunchKernelGGL(attn_seq_bwd_kv_kernel<0>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128 + 3 * npad * 4), s, a, npad);
     if (int rc = check_launch("attention_seq_bwd kv")) return rc;

@@ -306,6 +306,7 @@ constexpr int LDS_LIMIT = 160 * 1024;
 template <int S>
 int launch_fwd(const sfcvit_attn_args &a, int npad, size_t lds, hipStream_t s) {
     if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&attn_wide_fwd_kernel<S>), LDS_LIMIT, "attention_wide attribute")) return rc;
+    note_attn_kernel("attn_wide_fwd_kernel<%d>", S);
     hipLaunchKernelGGL(attn_wide_fwd_kernel<S>, dim3(a.H, a.B), dim3(THREADS), lds, s, a, npad);
     return check_launch("attention_wide_fwd");
 }
@@ -314,6 +315,7 @@ template <int S>
 int launch_bwd(const sfcvit_attn_args &a, int npad, size_t lds_kv, size_t lds_q, hipStream_t s) {
     for (const void *k : {reinterpret_cast<const void *>(&attn_wide_bwd_kv_kernel<S>), reinterpret_cast<const void *>(&attn_wide_bwd_q_kernel<S>)})
         if (int rc = raise_lds_limit(k, LDS_LIMIT, "attention_wide attribute")) return rc;
+    note_attn_kernel("attn_wide_bwd_kv_kernel<%d>", S);
     hipLaunchKernelGGL(attn_wide_bwd_kv_kernel<S>, dim3(a.H, a.B), dim3(THREADS), lds_kv, s, a, npad);
     if (int rc = check_launch("attention_wide_bwd kv")) return rc;
     hipLaunchKernelGGL(attn_wide_bwd_q_kernel<S>, dim3(a.H, a.B), dim3(THREADS), lds_q, s, a, npad);

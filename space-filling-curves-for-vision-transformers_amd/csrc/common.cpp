@@ -7,6 +7,14 @@ namespace sfcvit {
 namespace {
 thread_local char g_err[512] = "";
 thread_local int g_gemm[5] = {0, 0, 0, 0, 0};
+thread_local char g_attn[96] = "none";
+}
+
+void note_attn_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_attn, sizeof(g_attn), fmt, ap);
+    va_end(ap);
 }
 
 bool gemm_fused_colsum() { return g_gemm[0] == 1 && (g_gemm[2] & 16); }
@@ -68,6 +76,12 @@ extern "C" int sfcvit_last_gemm_kernel(char *buf, int n) {
     case 4: snprintf(buf, size_t(n), "gemm_kernel<%s, %s, %s>", tf[g_gemm[1] & 1], tf[g_gemm[2] & 1], tf[g_gemm[3] & 1]); break;
     default: snprintf(buf, size_t(n), "none"); break;
     }
+    return SFCVIT_OK;
+}
+
+extern "C" int sfcvit_last_attn_kernel(char *buf, int n) {
+    if (!buf || n <= 0) return SFCVIT_EINVAL;
+    snprintf(buf, size_t(n), "%s", sfcvit::g_attn);
     return SFCVIT_OK;
 }
 

@@ -19,6 +19,9 @@ int raise_lds_limit(const void *kernel, int bytes, const char *what);
 // Which GEMM kernel the calling thread's last sfcvit_gemm launched (sfcvit_last_gemm_kernel formats it as the symbol
 // rocprofv3 shows): family 1 gemm8p_kernel<a, b>, 2 gemm8p_km_kernel, 3 gemm256_kernel<a, b, c, d>, 4 gemm_kernel<a, b, c>.
 void note_gemm_kernel(int family, int a = 0, int b = 0, int c = 0, int d = 0);
+// Which attention kernel the calling thread's last sfcvit_attention_fwd / _bwd launched (its main kernel, named as
+// rocprofv3 names it); fmt is printf-style.
+void note_attn_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 bool gemm_fused_colsum();     // the kernel noted last was the 8-phase kernel with column sums in its epilogue
 bool gemm_fused_actmask();    // ... with the activation bit mask written (act) or read (dact) by its epilogue
 

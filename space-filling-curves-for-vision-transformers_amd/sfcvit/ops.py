@@ -33,9 +33,7 @@ class KernelTimer:
         out = fn()
         e1.record()
         if key.startswith("gemm "):         # key GEMM timings by the kernel symbol the library chose (as rocprofv3 names it)
-            buf = ctypes.create_string_buffer(96)
-            lib.sfcvit_last_gemm_kernel(buf, 96)
-            key = "gemm " + buf.value.decode()
+            key = "gemm " + last_gemm_kernel()
         self.records.setdefault(key, []).append((e0, e1, work))
         return out
 
@@ -51,10 +49,29 @@ class KernelTimer:
 
 
 TIMER = None
+KERNEL_LOG = None     # tests: set to a list and every GEMM / attention launch appends the kernel symbol the library chose
+
+
+def last_gemm_kernel():
+    buf = ctypes.create_string_buffer(96)
+    lib.sfcvit_last_gemm_kernel(buf, 96)
+    return buf.value.decode()
+
+
+def last_attn_kernel():
+    buf = ctypes.create_string_buffer(96)
+    lib.sfcvit_last_attn_kernel(buf, 96)
+    return buf.value.decode()
 
 
 def _launch(key, work, fn):
-    return fn() if TIMER is None else TIMER.launch(key, work, fn)
+    out = fn() if TIMER is None else TIMER.launch(key, work, fn)
+    if KERNEL_LOG is not None:
+        if key.startswith("gemm "):
+            KERNEL_LOG.append(last_gemm_kernel())
+        elif key.startswith("attn"):
+            KERNEL_LOG.append(last_attn_kernel())
+    return out
 
 
 def _stream():

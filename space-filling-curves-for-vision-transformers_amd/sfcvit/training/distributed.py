@@ -15,14 +15,39 @@ gradients per step, i.e. ~0.4-2.5 ms on the wire against >= 20 ms of backward, s
 few large buckets (default 32 MB: the last one, which cannot overlap with anything, costs ~0.2 ms) keep per-collective latency negligible and every
 link busy.
 """
+import datetime
+import faulthandler
 import os
 import sys
+import threading
 import time
 
 import torch
 import torch.distributed as dist
 
 _DEBUG = os.environ.get("SFCVIT_DDP_DEBUG", "0") == "1"      # one stderr line per collective launched / waited for
+# Every wait on a collective is bounded: a rank that does not get its bucket within this many seconds reports which
+# bucket of which step it was waiting for and leaves with a non-zero exit code (a stuck collective otherwise holds the
+# whole lease: VERDICT r2 #5).  Also handed to init_process_group by bench.py / main.py (dist_timeout()).
+DIST_TIMEOUT_S = float(os.environ.get("SFCVIT_DIST_TIMEOUT", "120"))
+
+
+def dist_timeout():
+    return datetime.timedelta(seconds=DIST_TIMEOUT_S)
+
+
+class CollectiveTimeout(RuntimeError):
+    pass
+
+
+def check_rehearsal_layout(backend, world, ranks_on_this_device):
+    """gloo ranks that SHARE one GPU are a functional rehearsal of the data-parallel path on a one-GPU box, nothing
+    more; more than two of them on a card are refused: the launch that tried four (gpurun_out/r2_4rank.err)
+    sat in its first hook-launched all-reduce until the lease ended."""
+    if backend == "gloo" and ranks_on_this_device > 2:
+        raise RuntimeError(f"{ranks_on_this_device} gloo ranks on one GPU (world {world}): refused.  The gloo rehearsal is "
+                           "supported for at most 2 ranks per device (DESIGN.md §6); use the CPU tests for more ranks, or one "
+                           "GPU per rank with the default backend (nccl = RCCL).")
 
 
 def _dbg(msg):
@@ -42,6 +67,18 @@ class GradReducer:
         self._hooks = []
         self._param_bucket = {}
         self._wait_events = None     # reset_stats(): (before, after) event pairs around finish()'s waits
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.timeout_s = DIST_TIMEOUT_S
+        self.step_no = 0
+        # gloo has no device path worth the name: given CUDA tensors it stages them through host memory on threads and
+        # streams of its own, and with hook-launched collectives racing the rest of backward for the card that is where
+        # the four-rank rehearsal stalled.  Under gloo the reducer therefore stages the flat gradient
+        # through ONE pinned host buffer itself, at finish(), bucket by bucket with blocking, bounded waits:
+        # no overlap (it is a rehearsal), the same buckets, the same arithmetic, the same result on every rank.
+        self._host_staged = None     # decided at _install (needs the flat buffer's device)
+        self._host_buf = None
+        self._watch = None           # RCCL: [(step, bucket, handle, t_launch)] watched by a daemon thread
+        self._watch_lock = threading.Lock()
         optimizer.grad_scale = 1.0 / self.world
 
     # -- bucket plan over the flat gradient buffer ------------------------------------------
@@ -76,15 +113,38 @@ class GradReducer:
                 self._param_bucket[id(p)] = len(self.buckets) - 1
         for _, _, p in views:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._host_staged = self.world > 1 and self.backend == "gloo" and self.opt.flat_grad.is_cuda
         if self.world > 1:
             # replicas must start identical: rank 0's parameters win (same-seed construction already gives that; a
-            # model built or loaded differently on some rank would otherwise drift silently)
-            _dbg("broadcast parameters")
-            dist.broadcast(self.opt.flat_param, src=0, group=self.group)
-            _dbg("broadcast done")
+            # model built or loaded differently on some rank would otherwise drift silently).  With fp32 master weights
+            # it is the MASTER that is broadcast and the bf16 parameters follow from it: after `--resume` rank 0's master
+            # carries the sub-bf16-ulp part of the checkpointed weights, which a broadcast of the rounded bf16 parameters
+            # followed by master <- param would throw away on every rank.
             master = getattr(self.opt, "master", None)
+            src = master if master is not None else self.opt.flat_param
+            _dbg("broadcast parameters" + (" (fp32 master)" if master is not None else ""))
+            self._broadcast(src)
+            _dbg("broadcast done")
             if master is not None:
-                master.copy_(self.opt.flat_param)
+                self.opt.flat_param.copy_(master)
+
+    def _broadcast(self, t):
+        if self.backend == "gloo" and t.is_cuda:          # host-staged, as the gradient buckets
+            h = t.cpu()
+            self._bounded(dist.broadcast(h, src=0, group=self.group, async_op=True), "parameter broadcast")
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=0, group=self.group)
+
+    def _bounded(self, work, what):
+        """Host-blocking wait with the reducer's timeout; raises CollectiveTimeout naming `what`."""
+        try:
+            ok = work.wait(datetime.timedelta(seconds=self.timeout_s))
+        except RuntimeError as e:                            # gloo raises on timeout
+            raise CollectiveTimeout(f"rank {dist.get_rank()}: {what} did not complete within {self.timeout_s:.0f} s "
+                                    f"(SFCVIT_DIST_TIMEOUT): {e}") from e
+        if ok is False:
+            raise CollectiveTimeout(f"rank {dist.get_rank()}: {what} did not complete within {self.timeout_s:.0f} s")
 
     def begin_step(self):
         self._handles = []
@@ -104,9 +164,38 @@ class GradReducer:
         if self.world == 1:
             return
         s, e = self.buckets[b]
+        if self._host_staged:                    # gloo rehearsal: reduced at finish(), through the host buffer
+            self._handles.append((b, None))
+            return
         _dbg(f"launch bucket {b} [{s}:{e}] (#{len(self._handles)} of this step)")
-        self._handles.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM,
-                                             group=self.group, async_op=True))
+        h = dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append((b, h))
+        if self.backend == "nccl":
+            self._watch_add(b, h)
+
+    # -- RCCL: waits are stream waits (the host runs ahead), so the bound is kept by a watcher thread ----------------
+    def _watch_add(self, b, h):
+        with self._watch_lock:
+            if self._watch is None:
+                self._watch = []
+                threading.Thread(target=self._watcher, name="sfcvit-collective-watch", daemon=True).start()
+            self._watch.append((self.step_no, b, h, time.monotonic()))
+
+    def _watcher(self):
+        while True:
+            time.sleep(1.0)
+            now = time.monotonic()
+            with self._watch_lock:
+                self._watch = [w for w in self._watch if not w[2].is_completed()]
+                late = [w for w in self._watch if now - w[3] > self.timeout_s]
+            if late:
+                step, b, _, t0 = late[0]
+                s, e = self.buckets[b]
+                print(f"[sfcvit] rank {dist.get_rank()}: all-reduce of gradient bucket {b} [{s}:{e}] launched in step {step} has "
+                      f"not completed after {now - t0:.0f} s (SFCVIT_DIST_TIMEOUT = {self.timeout_s:.0f}); {len(late)} collective(s) "
+                      "overdue.  Exiting with code 4.", file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                os._exit(4)
 
     def finish(self):
         """Block the compute stream on every outstanding collective.  On the first step (flat
@@ -128,15 +217,35 @@ class GradReducer:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for i, h in enumerate(self._handles):
-            _dbg(f"wait #{i}")
-            h.wait()
+        if self._host_staged and self._handles:
+            self._reduce_through_host()
+        else:
+            for i, (b, h) in enumerate(self._handles):
+                _dbg(f"wait #{i} (bucket {b})")
+                if self.backend == "nccl":
+                    h.wait()                     # stream wait only; bounded by the watcher thread
+                else:
+                    self._bounded(h, f"all-reduce of gradient bucket {b} {list(self.buckets[b])} (collective #{i} of step {self.step_no})")
         _dbg("step reduced")
+        self.step_no += 1
         if timed:
             e1.record()
             self._wait_events.append((e0, e1))
         self._handles = []
         self._pending = None
+
+    def _reduce_through_host(self):
+        g = self.opt.flat_grad
+        if self._host_buf is None:
+            self._host_buf = torch.empty(g.shape, dtype=g.dtype, pin_memory=True)
+        order = [b for b, _ in self._handles]                 # the order the hooks completed the buckets in (same on every rank)
+        self._host_buf.copy_(g)                               # D2H on the compute stream; blocks the host until it is there
+        for i, b in enumerate(order):
+            s, e = self.buckets[b]
+            _dbg(f"host-staged all-reduce #{i}: bucket {b} [{s}:{e}]")
+            work = dist.all_reduce(self._host_buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._bounded(work, f"all-reduce of gradient bucket {b} [{s}:{e}] (collective #{i} of step {self.step_no}, host-staged gloo)")
+        g.copy_(self._host_buf)
 
     # -- measurement (bench.py --gpus N) ------------------------------------------------------
     def reset_stats(self):
@@ -155,11 +264,14 @@ class GradReducer:
                "bytes_per_step": int(self.opt.flat_grad.numel() * self.opt.flat_grad.element_size()) if self.buckets else 0,
                "exposed_ms_per_step": round(exposed, 4)}
         if self.world > 1 and self.buckets:
-            scratch = torch.zeros_like(self.opt.flat_grad)
+            scratch = torch.zeros_like(self._host_buf if self._host_staged else self.opt.flat_grad)
             def run():
                 hs = [dist.all_reduce(scratch[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for s, e in self.buckets]
-                for h in hs:
-                    h.wait()
+                for b, h in enumerate(hs):
+                    if self.backend == "nccl":
+                        h.wait()
+                    else:
+                        self._bounded(h, f"stand-alone all-reduce of bucket {b}")
             run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

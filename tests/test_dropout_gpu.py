@@ -108,10 +108,20 @@ def test_attention_dropout(ops, B, N, H):
     close(dqkv, qf.grad, rel=1 / 48, abs_scale=1 / 24)
 
 
-def test_encoder_layer_training_mode_against_masked_reference(ops):
+# Shapes: a small ragged one (M = 136: the generic kernels) and ViT-B's widths at batch 64 -- M = 12 544 = 56 * 224 =
+# 49 * 256 rows is the smallest ViT-B batch that takes the production dispatch both ways (persistent 8-phase GEMM with
+# 224-row tiles forward, the per-step transposed weight for dX, the one-pass attention backward with 13 key fragments),
+# i.e. the kernels bench.py times at batch 256 in training mode (VERDICT r2 #1a).
+BENCHED_KERNELS = {"gemm8p_kernel<7, 0>", "gemm8p_kernel<7, 6>", "gemm8p_kernel<7, 35>", "gemm8p_kernel<7, 56>",
+                   "gemm8p_kernel<7, 4>", "gemm8p_km_kernel", "attn_seq_fwd_kernel<13>", "attn_seq_bwd_fused_kernel<13, true>"}
+
+
+@pytest.mark.parametrize("B,N,D,H,Fd,expect", [(2, 68, 128, 2, 256, None), (64, 196, 768, 12, 3072, BENCHED_KERNELS)],
+                         ids=["small", "vit_b_batch64"])
+def test_encoder_layer_training_mode_against_masked_reference(ops, B, N, D, H, Fd, expect):
     import sfcvit.functional as F
     g = torch.Generator(device="cuda").manual_seed(5)
-    B, N, D, H, Fd, p = 2, 68, 128, 2, 256, 0.1
+    p = 0.1
     seeds = (11, 22, 33, 44)
     r = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc)
     x = bf(r(B, N, D))
@@ -122,8 +132,15 @@ def test_encoder_layer_training_mode_against_masked_reference(ops):
     dy = bf(r(B, N, D))
     order = ["in_w", "in_b", "out_w", "out_b", "n1_w", "n1_b", "w1", "b1", "w2", "b2", "n2_w", "n2_b"]
     leaves = [x.clone().requires_grad_(True)] + [P[k].clone().requires_grad_(True) for k in order]
-    y = F._EncoderLayer.apply(*leaves, H, 1e-5, p, seeds, None)        # scale None = 1 / sqrt(head dim)
-    y.backward(dy)
+    ops.KERNEL_LOG = []
+    try:
+        y = F._EncoderLayer.apply(*leaves, H, 1e-5, p, seeds, None)        # scale None = 1 / sqrt(head dim)
+        y.backward(dy)
+        ran = set(ops.KERNEL_LOG)
+    finally:
+        ops.KERNEL_LOG = None
+    if expect is not None:
+        assert expect <= ran, (sorted(expect - ran), sorted(ran))
 
     # fp32 reference with the same masks
     M = B * N
