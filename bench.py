@@ -186,9 +186,12 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="replay the whole training step from one hipGraph")
     args = ap.parse_args()
-    if os.environ.get("SFCVIT_BENCH_WATCHDOG"):          # seconds: dump every thread's Python stack to stderr if still running then
+    # Deadline: a run still going after this many seconds dumps every thread's Python stack to stderr and exits with
+    # code 1 instead of holding the GPU lease (SFCVIT_BENCH_WATCHDOG; default for multi-rank runs: 900 s; 0 = off).
+    watchdog = int(os.environ.get("SFCVIT_BENCH_WATCHDOG", "900" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "0"))
+    if watchdog > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["SFCVIT_BENCH_WATCHDOG"]), repeat=True)
+        faulthandler.dump_traceback_later(watchdog, exit=True)
 
     if args.cpu_only:
         wl = args.workload or "vit_tiny16_32_raster"
@@ -216,10 +219,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        from sfcvit.training.distributed import check_rehearsal_layout, dist_timeout
+        # ranks that share this card: with SFCVIT_FORCE_DEVICE every rank of the node, otherwise one
+        check_rehearsal_layout(backend, world, world if "SFCVIT_FORCE_DEVICE" in os.environ else 1)
+        # every collective is bounded (SFCVIT_DIST_TIMEOUT, default 120 s): the backend's own watchdog gets the same limit
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=dist_timeout())
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=dist_timeout())
         assert dist.get_world_size() == args.gpus, "process group size != --gpus"
 
     from sfcvit import ops

@@ -90,7 +90,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        from sfcvit.training.distributed import dist_timeout
+        dist.init_process_group("nccl", device_id=device, timeout=dist_timeout())      # bounded collectives (SFCVIT_DIST_TIMEOUT)
     seed = 42                                                   # main.py:151-154
     torch.manual_seed(seed)
     np.random.seed(seed + rank)

@@ -46,6 +46,10 @@ class _Hierarchical(nn.Module):
             D = self.levels[0].embed_dim
             ppt = [lv.input_dim // x.shape[1] for lv in self.levels]
             ok = all(lv.embed_dim == D and lv.input_dim % x.shape[1] == 0 for lv in self.levels)
+            # the fused kernel also needs every level's tokens to cover the image exactly (N * P_l == H * W, checked again by
+            # sfcvit_hier_tokenizer_fwd); a level whose grouped pre-patches do not takes the composed path
+            img = self.levels[0]._geom[0]
+            ok = ok and all(lv.n_patches * p == img * img for lv, p in zip(self.levels, ppt))
             self._fuse_ok = ok and ops.hier_tokenizer_supported(len(self.levels), D, x.shape[1], ppt)
             self._fuse_key = key
         return self._fuse_ok

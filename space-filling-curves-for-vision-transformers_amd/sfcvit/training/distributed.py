@@ -204,6 +204,8 @@ class GradReducer:
         if self.buckets is None:
             if self.opt.flat_grad is None:
                 self.opt._build()
+            else:
+                self.opt.adopt_all()             # layout built earlier (load_state_dict): gradients produced outside the slots move in
             self._install()
             if self.world > 1:
                 for b in range(len(self.buckets)):

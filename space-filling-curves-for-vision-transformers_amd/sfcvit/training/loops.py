@@ -50,6 +50,8 @@ def _plain_epoch(model, train_loader, criterion, optimizer, scheduler, device):
     correct = torch.zeros((), device=device)
     for images, labels in train_loader:
         images, labels = images.to(device), labels.to(device)
+        if hasattr(optimizer, "begin_step"):
+            optimizer.begin_step()
         optimizer.zero_grad()
         outputs = model(images)
         loss = criterion(outputs.float(), labels)
@@ -102,6 +104,8 @@ def train_with_mixup_or_cutmix(model, train_loader, criterion, optimizer, schedu
             total_loss += loss.float() * images.size(0)
             total_samples += images.size(0)
             continue
+        if hasattr(optimizer, "begin_step"):
+            optimizer.begin_step()       # a batch the graph cannot replay (odd size): the device step state advances here
         optimizer.zero_grad()
         if reducer is not None:
             reducer.begin_step()

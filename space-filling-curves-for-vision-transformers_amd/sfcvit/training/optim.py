@@ -113,6 +113,7 @@ class FusedAdamW(FlatGradBuffer):
         self.master = self.m = self.v = self._sumsq = None
         self.dev_state = None            # use_device_state(): int32[8] device tensor (include/sfcvit.h, sfcvit_step_advance)
         self._seed_base = 0
+        self._advanced_eagerly = False   # begin_step() ran outside a stream capture: step() then counts on the host too
 
     @property
     def lr(self):
@@ -138,9 +139,27 @@ class FusedAdamW(FlatGradBuffer):
         ops.STEP_STATE = self.dev_state
         return self.dev_state
 
+    def release_device_state(self):
+        """Back to host-side step state (the default): later models / optimizers of this process draw their dropout seeds
+        from torch's generator again instead of this optimizer's device offset (ops.STEP_STATE is process-global).  A
+        hipGraph captured with the device state must not be replayed afterwards; GraphedTrainStep.close() calls this."""
+        if self.dev_state is not None:
+            if ops.STEP_STATE is self.dev_state:
+                ops.STEP_STATE = None
+            self.dev_state = None            # step_count has mirrored the device counter all along
+
     def advance(self):
         """Device-state mode: begin a training step (step += 1, new dropout seed offset, bias corrections)."""
         ops.step_advance(self.dev_state, self.betas[0], self.betas[1], self._seed_base)
+
+    def begin_step(self):
+        """First call of EVERY training step (train_step, the epoch loops and GraphedTrainStep make it).  Host-state
+        mode: nothing to do.  Device-state mode: advance the device counters; when that happens eagerly (not inside a
+        stream capture -- e.g. an odd-sized last batch that cannot replay the graph) step() also keeps the host mirror
+        of the step count in line, so checkpoints and later replays agree with the device."""
+        if self.dev_state is not None:
+            self.advance()
+            self._advanced_eagerly = not torch.cuda.is_current_stream_capturing()
 
     def _check(self, p):
         if p.dtype != torch.bfloat16 or not p.is_cuda:
@@ -158,8 +177,9 @@ class FusedAdamW(FlatGradBuffer):
             self._build()
         else:
             self.adopt_all()
-        if self.dev_state is None:
-            self.step_count += 1         # device-state mode: advance() counts (and GraphedTrainStep mirrors it here)
+        if self.dev_state is None or self._advanced_eagerly:
+            self.step_count += 1         # device-state mode, captured: the replay's advance() counts and GraphedTrainStep mirrors it
+            self._advanced_eagerly = False
         sumsq = None
         if self.max_grad_norm is not None:
             self._sumsq.zero_()

@@ -47,8 +47,8 @@ class GraphedTrainStep:
         side.wait_stream(cur)
         with torch.cuda.stream(side):                 # warm up off the default stream (allocator pools, flat buffers,
             for _ in range(max(1, warmup)):           # LDS attributes, tile-queue slots: nothing of that may happen in capture)
-                self._step()
-                self._after()
+                self._step()                          # eager: optimizer.step() counts on the host itself
+                self._after(replayed=False)
         cur.wait_stream(side)
         if snap is not None:
             self._restore(snap)
@@ -58,7 +58,7 @@ class GraphedTrainStep:
             self.loss = self._step()
 
     def _step(self):                                  # train_step() below, keeping the logits
-        self.opt.advance()
+        self.opt.begin_step()
         self.opt.zero_grad()
         logits = self.model(self.images)
         loss = F.soft_target_cross_entropy(logits, self.targets)
@@ -92,19 +92,37 @@ class GraphedTrainStep:
                 setattr(self.sched, k, v)
         o.lr = s["lr"]
 
-    def _after(self):
-        self.opt.step_count += 1                      # host mirror of the device counter (checkpoints read it)
+    def _after(self, replayed=True):
+        if replayed:
+            self.opt.step_count += 1                  # host mirror of the device counter (checkpoints read it)
         if self.sched is not None:
             self.sched.step()                         # sets optimizer.lr -> one tiny device write, outside the graph
 
     def __call__(self):
+        if self.graph is None:
+            raise RuntimeError("GraphedTrainStep was closed")
         self.graph.replay()
         self._after()
         return self.loss
 
+    def close(self):
+        """Drop the graph and hand the step state back to the host (FusedAdamW.release_device_state): the optimizer, the
+        model and anything else in the process then behave as before the graphed step existed."""
+        self.graph = None
+        self.opt.release_device_state()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
 
 def train_step(model, images, soft_targets, optimizer, scheduler=None, reducer=None):
     """One optimisation step; returns the (device, un-synchronised) loss."""
+    if hasattr(optimizer, "begin_step"):
+        optimizer.begin_step()           # device-resident step state (after a GraphedTrainStep): counters advance here
     optimizer.zero_grad()
     if reducer is not None:
         reducer.begin_step()

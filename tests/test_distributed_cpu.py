@@ -92,3 +92,107 @@ def test_bucket_plan():
     assert GradReducer.plan([10, 100, 1000, 8, 50], 128) == [(0, 2), (2, 3), (3, 5)]
     assert GradReducer.plan([8], 1) == [(0, 1)]
     assert GradReducer.plan([], 64) == []
+
+
+# ---- bounded waits, the rehearsal guard, fp32 master after a resume ---------------------
+def _stuck_worker(rank, world, port, out):
+    """Rank 1 never reduces its second step: rank 0's wait must end in CollectiveTimeout naming the bucket."""
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SFCVIT_DIST_TIMEOUT="3")
+    from sfcvit.training.distributed import CollectiveTimeout, GradReducer, dist_timeout
+    from sfcvit.training.optim import FlatGradBuffer
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=dist_timeout())
+    model, _ = _model()
+    buf = FlatGradBuffer(list(model.parameters()))
+    red = GradReducer(buf, bucket_bytes=4096)
+    msg = ""
+    for step in range(2):
+        x, y = _batch(rank, step)
+        buf.zero_grad()
+        red.begin_step()
+        if step == 1 and rank == 1:
+            import time
+            time.sleep(8)                       # alive, but not taking part (the hooks of its backward would launch its share)
+            break
+        ((model(x) - y) ** 2).mean().backward()
+        try:
+            red.finish()
+        except CollectiveTimeout as e:
+            msg = str(e)
+            break
+    if rank == 0:
+        torch.save({"msg": msg}, out)
+
+
+@pytest.mark.timeout(120)
+def test_a_stuck_collective_raises_with_the_bucket_index(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    try:
+        mp.spawn(_stuck_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    except Exception:
+        pass                                    # teardown of a half-finished group may complain; rank 0's report is what counts
+    msg = torch.load(out)["msg"]
+    assert "all-reduce of gradient bucket" in msg and "of step 1" in msg and "within 3 s" in msg, msg
+
+
+def test_more_than_two_gloo_ranks_on_one_device_are_refused():
+    sys.path.insert(0, PKG)
+    from sfcvit.training.distributed import check_rehearsal_layout
+    check_rehearsal_layout("gloo", 2, 2)
+    check_rehearsal_layout("nccl", 8, 1)
+    check_rehearsal_layout("gloo", 4, 1)        # CPU tensors / one rank per device: fine
+    with pytest.raises(RuntimeError, match="4 gloo ranks on one GPU"):
+        check_rehearsal_layout("gloo", 4, 4)
+
+
+class _MasterBuffer:
+    """FlatGradBuffer with fp32 master weights as FusedAdamW keeps them (that class needs a GPU): bf16 parameters and
+    gradients, master = what a checkpoint restored."""
+
+
+def _resume_worker(rank, world, port, out):
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sfcvit.training.distributed import GradReducer
+    from sfcvit.training.optim import FlatGradBuffer
+
+    class Buf(FlatGradBuffer):
+        def _built(self):
+            self.master = self.flat_param.float()
+
+    torch.manual_seed(7)
+    model = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.ReLU(), torch.nn.Linear(40, 8)).to(torch.bfloat16)
+    buf = Buf(list(model.parameters()))
+    buf._build(list(model.parameters()))
+    # "--resume": rank 0 restores fp32 master weights that carry bits below bf16's; rank 1 holds something else entirely
+    g = torch.Generator().manual_seed(5)
+    ckpt = torch.randn(buf.master.shape, generator=g) * 0.1
+    buf.master.copy_(ckpt if rank == 0 else torch.zeros_like(ckpt))
+    buf.flat_param.copy_(buf.master)
+    red = GradReducer(buf, bucket_bytes=1024)
+    x, y = _batch(rank, 0)
+    buf.zero_grad()
+    red.begin_step()
+    ((model(x.bfloat16()).float() - y) ** 2).mean().backward()
+    red.finish()                                 # first reduced step: installs the hooks, broadcasts rank 0's state
+    torch.save({"master": buf.master.clone(), "param": buf.flat_param.clone(), "ckpt": ckpt, "grad": buf.flat_grad.clone()}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_first_reduced_step_keeps_the_checkpointed_fp32_master(tmp_path):
+    """on a multi-rank resume the first step's broadcast must carry the fp32 master, not the bf16-rounded
+    parameters -- afterwards every rank's master is bit-identical to the checkpoint and its bf16 parameters are the
+    rounded master.  (bf16 gradients reduce over gloo as well.)"""
+    out = str(tmp_path / "rank")
+    mp.spawn(_resume_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for r in (r0, r1):
+        assert torch.equal(r["master"], r0["ckpt"])
+        assert torch.equal(r["param"], r0["ckpt"].to(torch.bfloat16))
+    assert (r0["ckpt"] - r0["ckpt"].to(torch.bfloat16).float()).abs().max() > 0     # the checkpoint does carry sub-bf16 bits
+    assert torch.equal(r0["grad"], r1["grad"]) and r0["grad"].dtype == torch.bfloat16 and r0["grad"].abs().sum() > 0

@@ -51,12 +51,20 @@ def _run(model, x, tgt, dev, reducer_world):
     return losses, master, (len(red.buckets) if red else 0)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend="nccl"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from sfcvit.training.distributed import dist_timeout
+    card = rank if backend == "nccl" else 0                  # gloo rehearsal: both ranks share card 0
+    torch.cuda.set_device(card)
+    dev = torch.device("cuda", card)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=dist_timeout())
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=dist_timeout())
     model, x, tgt = _setup()
     per = x.shape[0] // world
     losses, master, nb = _run(model, x[rank * per:(rank + 1) * per], tgt[rank * per:(rank + 1) * per], dev, world)
@@ -66,12 +74,16 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_over_rccl_match_one_rank_on_the_concatenated_batch(tmp_path):
-    if torch.cuda.device_count() < 2:
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_two_ranks_match_one_rank_on_the_concatenated_batch(tmp_path, backend):
+    """backend nccl: two GPUs over RCCL (skipped on a one-GPU box).  backend gloo: the rehearsal that always runs -- two
+    ranks of the HIP step on ONE card, gradients reduced through the host (GradReducer's host-staged gloo mode), so the
+    N > 1 step has a correctness check that is never skipped (VERDICT r2 #8)."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (RCCL over xGMI)")
     import torch.multiprocessing as mp
     out = str(tmp_path / "rank")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, backend), nprocs=2, join=True)
     r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
     assert r0["buckets"] > 1
     for k in r0["master"]:

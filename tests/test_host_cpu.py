@@ -351,3 +351,19 @@ def test_hier_tokenizer_envelope_and_padded_head_dims():
     assert not ok(2, 128, 3, [16])                     # one entry per level
     assert [ops.padded_head_dim(h) for h in (16, 32, 48, 64, 96, 128, 160, 192, 200, 256)] == [64, 64, 64, 64, 128, 128, 192, 192, 256, 256]
     assert ops.padded_head_dim(257) is None
+
+
+def test_hierarchical_fusable_requires_levels_that_cover_the_image():
+    """`_fusable` must send a level whose tokens do not cover the image exactly (N * P_l != H * W) to the
+    composed path instead of letting sfcvit_hier_tokenizer_fwd reject it.  Host arithmetic only (a stub stands in for
+    the CUDA input)."""
+    from sfcvit.tokenizers.multiscale import HierarchicalMortonEmbedding
+
+    class X:
+        is_cuda, shape = True, (2, 3, 32, 32)
+
+    tok = HierarchicalMortonEmbedding(32, 3, [16, 4, 1], 256)
+    assert tok._fusable(X())
+    tok._fuse_key = None                                           # the decision is cached per channel count
+    tok.levels[2].input_dim *= 2                                   # a level with twice the pixels per token: 64 * 32 != 32 * 32
+    assert not tok._fusable(X())

@@ -586,14 +586,14 @@ def test_graphed_train_step_replays_bit_exactly_and_draws_new_masks():
         opt_e.use_device_state(seed_base=4242)
         eager = []
         for _ in range(6):
-            opt_e.advance()
-            eager.append(float(train_step(model_e, x, tgt, opt_e)))
+            eager.append(float(train_step(model_e, x, tgt, opt_e)))       # begin_step() advances the device state
         model_g, opt_g = fresh()
         opt_g.use_device_state(seed_base=4242)
         step = GraphedTrainStep(model_g, x.clone(), tgt.clone(), opt_g, warmup=2, preserve_state=False)   # 2 eager steps that count, then capture
         graphed = [float(step()) for _ in range(4)]
         assert graphed == eager[2:], (graphed, eager)
         assert opt_g.step_count == 6 and int(opt_g.dev_state[1]) == 6
+        assert opt_e.step_count == 6 and int(opt_e.dev_state[1]) == 6     # eager steps in device-state mode count on both sides
         for (k, a), (_, b) in zip(model_e.state_dict().items(), model_g.state_dict().items()):
             assert torch.equal(a, b), k
         assert torch.equal(opt_e.master, opt_g.master) and torch.equal(opt_e.v, opt_g.v)
@@ -602,6 +602,10 @@ def test_graphed_train_step_replays_bit_exactly_and_draws_new_masks():
             opt_g.advance(); a = model_g(x).float()
             opt_g.advance(); b = model_g(x).float()
         assert not torch.equal(a, b)
+        step.close()                                   # the graphed step owns the device state's lifetime
+        assert ops.STEP_STATE is None and opt_g.dev_state is None
+        with pytest.raises(RuntimeError, match="closed"):
+            step()
     finally:
         ops.STEP_STATE = None
 
@@ -618,9 +622,13 @@ def test_graphed_epoch_loop_trains_like_the_eager_loop_and_leaves_state_untouche
     cfg, _ = MODEL_CASES["hilbert32_1d"]
     g = torch.Generator().manual_seed(0)
     xs, ys = torch.randn(3, 8, 3, 32, 32, generator=g), torch.randint(0, cfg.num_classes, (3, 8), generator=g)
+    # ... and a last, smaller batch (a real DataLoader's tail): it cannot replay the graph and runs eagerly IN device-state
+    # mode -- its step must advance the device counters and the host mirror like any other
+    x_tail, y_tail = torch.randn(5, 3, 32, 32, generator=g), torch.randint(0, cfg.num_classes, (5,), generator=g)
+    batches = list(zip(xs, ys)) + [(x_tail, y_tail)]
 
     class Loader(list):
-        dataset = range(24)
+        dataset = range(29)
 
     def epoch(graph):
         m = build_model(cfg)
@@ -636,12 +644,10 @@ def test_graphed_epoch_loop_trains_like_the_eager_loop_and_leaves_state_untouche
             assert all(torch.equal(a, b) for a, b in zip(before, m.parameters()))
             assert o.step_count == 0 and int(o.dev_state[1]) == 0 and sch.n == 0 and not o.m.any() and not o.v.any()
             assert torch.equal(o.master, o.flat_param.float()) and o.lr == sch.lr_at(0)
-        else:                                                          # eager, device-state mode: advance() opens every step
-            real = o.zero_grad
-            o.zero_grad = lambda *a_, **k_: (o.advance(), real(*a_, **k_))[1]
         torch.manual_seed(11)
         np.random.seed(11)
-        out = train_with_mixup_or_cutmix(m, Loader(zip(xs, ys)), SoftTargetCrossEntropy(), o, sch, "cuda", graphed=gs)
+        out = train_with_mixup_or_cutmix(m, Loader(batches), SoftTargetCrossEntropy(), o, sch, "cuda", graphed=gs)
+        assert o.step_count == 4 and int(o.dev_state[1]) == 4 and sch.n == 4      # three replays (or eager steps) + the tail
         return out, [p.detach().float().clone() for p in m.parameters()], o.master.clone()
 
     try:
