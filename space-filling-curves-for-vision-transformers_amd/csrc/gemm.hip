@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ w
 
 int gemm256_dispatch(const sfcvit_gemm_args &a, int splits, int k_per_split, hipStream_t s);   // gemm256.hip
 int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s);                        // gemm8p.hip
-int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_used, hipStream_t s);
+int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_used, int *k_done, hipStream_t s);
 
 }  // namespace sfcvit
 
@@ -139,7 +139,7 @@ extern "C" int64_t sfcvit_gemm_workspace(int M, int N, int splitk) {
 
 extern "C" int64_t sfcvit_gemm_colsum_workspace(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    const int64_t fused = (int64_t(M) / 96 + 2) * N * int64_t(sizeof(float));       // partial rows of the 8-phase epilogue (192-row tiles)
+    const int64_t fused = (int64_t(M) / 96 + 2) * N * int64_t(sizeof(float));       // partial rows of the 8-phase epilogue: 2 per row tile, <= 2 ceil(M / 192)
     const int64_t separate = sfcvit_colsum_workspace(M, N);
     return fused > separate ? fused : separate;
 }
@@ -211,9 +211,27 @@ static int gemm_impl(const sfcvit_gemm_args *a, void *stream) {
     if (a->force_generic == 0 || (a->force_generic >= 8 && a->force_generic <= 10)) {
         int p8 = gemm8p_dispatch(*a, splits, s);
         if (p8 >= 0) return p8;
-        int used = 0;
-        p8 = gemm8p_km_dispatch(*a, splits, &used, s);
+        int used = 0, k_done = 0;
+        p8 = gemm8p_km_dispatch(*a, splits, &used, &k_done, s);
         if (p8 > 0) return p8;
+        if (p8 == 0 && k_done < a->K) {
+            // the last K % 128 rows of both k-major operands: one more fp32 slab from the generic kernel, summed with the
+            // others in the same fixed order
+            sfcvit_gemm_args t = *a;
+            t.a = static_cast<const uint16_t *>(a->a) + size_t(k_done) * a->lda;
+            t.b = static_cast<const uint16_t *>(a->b) + size_t(k_done) * a->ldb;
+            t.K = a->K - k_done;
+            t.c = static_cast<float *>(a->workspace) + size_t(used) * a->M * a->N;
+            t.ldc = a->N;
+            t.c_is_f32 = 1;
+            t.splitk = 1;
+            t.workspace = nullptr;
+            t.workspace_bytes = 0;
+            t.force_generic = 1;
+            if (int rc = gemm_impl(&t, stream)) return rc;
+            note_gemm_kernel(2);                                 // what ran is the 8-phase weight-gradient kernel (+ its tail)
+            used++;
+        }
         if (p8 == 0) {
             const int64_t nvec = int64_t(a->M) * (a->N / 4);
             hipLaunchKernelGGL(splitk_reduce, dim3(unsigned((nvec + 255) / 256)), dim3(256), 0, s,

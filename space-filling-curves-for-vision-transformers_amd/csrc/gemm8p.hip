@@ -2,7 +2,8 @@
 // k-contiguous -- every forward GEMM of the encoder and (on the per-step transposed weight) every dX GEMM.
 //
 //   * tile (32*NI) x 256 x 64 with NI = 8, 7 or 6 (256, 224 or 192 rows: the height that wastes least of the last
-//     round of tiles on 256 CUs; M = 50176 = 196 * 256 = 224 * 224, ViT-L's 36864 = 192 * 192), 8 waves = 2 wave groups (row halves) x 4 column
+//     round of tiles on 256 CUs; M = 50176 = 196 * 256 = 224 * 224, ViT-L's 36864 = 192 * 192; any M >= one tile: the last
+//     row tile of a height that does not divide M overlaps the one before it), 8 waves = 2 wave groups (row halves) x 4 column
 //     blocks, wave tile (16*NI) x 64, 16x16x32 MFMA.
 //   * one workgroup per CU walks output tiles that it draws from a per-XCD atomic counter (tiles are dealt to the XCDs
 //     in chunks of 32 consecutive ones, so the workgroups of an XCD share A row panels in its L2).  Drawing instead of
@@ -177,7 +178,10 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     // keeps what those branches update -- the staging cursors -- in scalar registers
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 2, wc = wid & 3;
     const int q = lane >> 4, nl = lane & 15;
-    const int K = g.K, NT = g.N / 256, ntiles = (g.M / BM) * NT, KT = K / 64;
+    // M need not be a multiple of the tile height: the LAST row tile then starts at row M - BM, i.e. overlaps the one before
+    // it, and recomputes (bit-identically: same k order, masks are functions of the global row) and re-stores the rows
+    // they share -- no predication anywhere; only the column sums have to leave the shared rows out (epilogue).
+    const int K = g.K, NT = g.N / 256, ntiles = ((g.M + BM - 1) / BM) * NT, KT = K / 64, m_last = g.M - BM;
     const uint16_t *A = static_cast<const uint16_t *>(g.a);
     const uint16_t *B = static_cast<const uint16_t *>(g.b);
     // Tile queue.  XCD x (blockIdx % 8: where the dispatcher puts this workgroup, a locality heuristic only) owns the
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         c.tile = seq;                                          // position in this workgroup's sequence of tiles
         c.k0 = 0;
         if (tile < 0) tile = tile_first;                       // past the end: re-stage the first tile (never consumed)
-        c.p = is_a ? A + size_t(tile >> 16) * BM * g.lda : B + size_t(tile & 0xFFFF) * 256 * g.ldb;
+        c.p = is_a ? A + size_t(min((tile >> 16) * BM, m_last)) * g.lda : B + size_t(tile & 0xFFFF) * 256 * g.ldb;
         return c;
     };
     // Where the cursors go when they leave the current tile: the operand origins of the workgroup's next tile, worked
@@ -377,7 +381,8 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
             sm.ra = patch + r0 * 128 + ((ch ^ r0) << 4);
             sm.coff = long(r0 - ne) * g.ldc + (8 * ch - 16 * qe);
         }
-        const int m0 = (tile >> 16) * BM + wr * GR + ne, n0 = (tile & 0xFFFF) * 256 + wc * 64 + qe * 16;
+        const int m_new = (tile >> 16) * BM;                   // rows below it belong to the previous tile too (ragged M)
+        const int m0 = min(m_new, m_last) + wr * GR + ne, n0 = (tile & 0xFFFF) * 256 + wc * 64 + qe * 16;
         mfma_fence();
         float bv[16];                                           // this lane's 16 bias values, from the LDS copy
         if (has_bias) {
@@ -418,12 +423,15 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
                                acc[i][3][0], acc[i][3][1], acc[i][3][2], acc[i][3][3]};
                 epilogue_row<MASK>(g, m0 + 16 * i, n0, v, bv, side[i - i0], thresh, keep_scale, dact_scale, sm, rk_in0, rk_in1);
                 if (MASK & CSUM) {
+                    const bool own = m0 + 16 * i >= m_new;           // a row the overlapping last tile shares is summed once
 #pragma unroll
-                    for (int r = 0; r < 16; r++) cs[r] += v[r];      // the fp32 values that were just stored as bf16
+                    for (int r = 0; r < 16; r++) cs[r] += own ? v[r] : 0.f;      // the fp32 values that were just stored as bf16
                 }
             });
         };
-        if constexpr (NI == 8 && (MASK & (DROP | RES)) == (DROP | RES)) {   // no registers for 8 rows beside the hash
+        // no registers for the side operand of 8 rows beside the hash (DROP | RES) or beside the column sums (DACT | CSUM
+        // reading the stored activation rather than its bit mask)
+        if constexpr (NI == 8 && ((MASK & (DROP | RES)) == (DROP | RES) || (MASK & (DACT | CSUM | BITS)) == (DACT | CSUM))) {
             batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
             batch(std::integral_constant<int, 4>{}, std::integral_constant<int, NI>{});
         } else {
@@ -805,16 +813,19 @@ int launch_mask(const sfcvit_gemm_args &a, int mask, int grid, hipStream_t s) {
 
 // Weight-gradient form (both operands k-major, split-K into the workspace slabs).  Returns -1 when not eligible,
 // else a status; *splits_used = number of slabs written (the caller runs the ordered reduction over them).
-int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_used, hipStream_t s) {
+// k need not be a multiple of 128 (k = batch x tokens: 19 600 rows at batch 100): the kernel takes the largest multiple,
+// *k_done says how far it got, and the caller adds the remaining < 128 rows as one more slab (a slab is kept free for it).
+int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_used, int *k_done, hipStream_t s) {
     using namespace p8;
     if (!a.a_kmajor || !a.b_kmajor || splits_req < 2) return -1;
-    if (a.M % 256 || a.N % 256 || a.K % 128 || a.lda % 8 || a.ldb % 8) return -1;
+    if (a.M % 256 || a.N % 256 || a.K < 1024 || a.lda % 8 || a.ldb % 8) return -1;
     const int cus = device_cus();
     if (!cus) return -1;
-    const int tiles = (a.M / 256) * (a.N / 256), KT = a.K / 64;
+    const int Kb = a.K / 128 * 128, tail = a.K - Kb;
+    const int tiles = (a.M / 256) * (a.N / 256), KT = Kb / 64;
     int splits = cus / tiles;                                     // one workgroup per CU
     if (splits > splits_req) splits = splits_req;
-    const int64_t slabs_avail = a.workspace_bytes / (int64_t(a.M) * a.N * int64_t(sizeof(float)));
+    const int64_t slabs_avail = a.workspace_bytes / (int64_t(a.M) * a.N * int64_t(sizeof(float))) - (tail ? 1 : 0);
     if (splits > slabs_avail) splits = int(slabs_avail);
     if (splits < 2) return -1;
     int kps = ((KT + splits - 1) / splits + 1) / 2 * 2;           // k-tiles per split, even
@@ -822,8 +833,11 @@ int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_us
     if (splits < 2) return -1;
     if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_km_kernel), LDS_BYTES, "gemm8p_km attribute")) return rc;
     note_gemm_kernel(2);
-    hipLaunchKernelGGL(gemm8p_km_kernel, dim3((tiles * splits + 7) / 8 * 8), dim3(T), LDS_BYTES, s, a, kps, splits);
+    sfcvit_gemm_args body = a;
+    body.K = Kb;
+    hipLaunchKernelGGL(gemm8p_km_kernel, dim3((tiles * splits + 7) / 8 * 8), dim3(T), LDS_BYTES, s, body, kps, splits);
     *splits_used = splits;
+    *k_done = Kb;
     return check_launch("gemm8p_km");
 }
 
@@ -853,23 +867,28 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     const int nt = a.N / 256;
     long best = -1;
     int ni = 0;
+    // Any M >= one tile: a height that does not divide M makes the last row tile overlap its predecessor (kernel header),
+    // which costs that tile's share of recomputed rows, i.e. it is priced as one more tile.  The overlapping tile reads
+    // residual / aux_in rows another workgroup may be storing to if C aliases them: refused then.
+    const bool aliased = a.c == a.residual || a.c == a.aux_in;
     for (int cand : {8, 7, 6}) {
-        if (a.M % (32 * cand)) continue;
-        const long tiles = long(a.M / (32 * cand)) * nt;
+        if (a.M < 32 * cand || (a.M % (32 * cand) && aliased)) continue;
+        const long tiles = long((a.M + 32 * cand - 1) / (32 * cand)) * nt;
         const long cost = ((tiles + cus - 1) / cus) * cand;
         if (best < 0 || cost < best) { best = cost; ni = cand; }
     }
     if (!ni) return -1;
-    if (a.force_generic == 8) ni = (a.M % 256 == 0) ? 8 : ni;          // tests: pin the 256-row tile
-    if (a.force_generic == 9) { if (a.M % 224) return -1; ni = 7; }    // tests: pin the 224-row tile
-    if (a.force_generic == 10) { if (a.M % 192) return -1; ni = 6; }   // tests: pin the 192-row tile
+    if (a.force_generic == 8) { if (a.M < 256 || (a.M % 256 && aliased)) return -1; ni = 8; }    // tests: pin the 256-row tile
+    if (a.force_generic == 9) { if (a.M < 224 || (a.M % 224 && aliased)) return -1; ni = 7; }    // tests: pin the 224-row tile
+    if (a.force_generic == 10) { if (a.M < 192 || (a.M % 192 && aliased)) return -1; ni = 6; }   // tests: pin the 192-row tile
+    const int nparts = 2 * ((a.M + 32 * ni - 1) / (32 * ni));            // CSUM: one partial row per (row tile, wave group)
     if (mask & CSUM) {
-        const int64_t need = int64_t(a.M / (16 * ni)) * a.N * int64_t(sizeof(float));
+        const int64_t need = int64_t(nparts) * a.N * int64_t(sizeof(float));
         if (!a.workspace || a.workspace_bytes < need || (reinterpret_cast<uintptr_t>(a.workspace) & 15)) return -1;
     }
     const int rc = ni == 8 ? launch_mask<8>(a, mask, cus, s) : ni == 7 ? launch_mask<7>(a, mask, cus, s) : launch_mask<6>(a, mask, cus, s);
     if (rc == 0 && (mask & CSUM))
-        return launch_colsum_reduce(static_cast<const float *>(a.workspace), a.M / (16 * ni), a.N, a.colsum_out, a.colsum_bf16, s);
+        return launch_colsum_reduce(static_cast<const float *>(a.workspace), nparts, a.N, a.colsum_out, a.colsum_bf16, s);
     return rc;
 }
 

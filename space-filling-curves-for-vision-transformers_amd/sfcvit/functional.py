@@ -308,7 +308,7 @@ def attention(qkv, n_heads):
 
 def _fast_gemm_shape(M, N, K):
     """Shapes the persistent 8-phase GEMM takes (csrc/gemm8p.hip: gemm8p_dispatch)."""
-    return (M % 192 == 0 or M % 224 == 0 or M % 256 == 0) and N % 256 == 0 and K % 128 == 0 and K >= 256
+    return M >= 192 and N % 256 == 0 and K % 128 == 0 and K >= 256
 
 
 # ----------------------------------------------------------------------------

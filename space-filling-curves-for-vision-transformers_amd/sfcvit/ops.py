@@ -127,7 +127,7 @@ def auto_splitk(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if K < 2048:
         return 1
-    if M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and (M // 256) * (N // 256) <= 128:
+    if M % 256 == 0 and N % 256 == 0 and (M // 256) * (N // 256) <= 128:      # any K: the last K % 128 rows are one more slab
         # weight-gradient form of the 8-phase kernel: one workgroup per CU, tiles256 x splits <= 256
         s = min(64, 256 // ((M // 256) * (N // 256)))
         if s >= 2 and K // s >= 512:
@@ -270,7 +270,9 @@ def gemm_dx(dy, w, **kw):
     read k-major in place by the generic kernel."""
     M, K = dy.shape
     N = w.shape[1]
-    if M % 256 == 0 and N % 128 == 0 and K % 32 == 0 and K % 8 == 0:
+    # the persistent 8-phase kernel takes any M >= 192 (a last row tile that overlaps its predecessor); the LDS-DMA
+    # ring kernel before it needs whole 256-row tiles
+    if N % 128 == 0 and K % 32 == 0 and (M % 256 == 0 or (M >= 192 and N % 256 == 0 and K % 128 == 0 and K >= 256)):
         return gemm(dy, transpose(w), **kw)
     return gemm(dy, w, b_kmajor=True, **kw)
 

@@ -362,6 +362,72 @@ def test_gemm_persistent_kernel_epilogues(ops, mode, M):
         ops.gemm(a, w, bias=bias, act=ops.ACT_RELU, residual=res, force_generic=mode)
 
 
+@pytest.mark.parametrize("mode,M", [(8, 1000), (9, 1001), (10, 200), (0, 19600), (0, 49000)])
+def test_gemm_persistent_kernel_ragged_rows(ops, mode, M):
+    """M that no tile height divides (ViT-B at batch 100 / 250: 19 600 / 49 000 token rows; a last partial batch): the
+    persistent kernel's last row tile overlaps the one before it.  Every epilogue variant against the generic kernel
+    as in test_gemm_persistent_kernel_epilogues; the rows are bit-identical to the same rows of a single launch on a
+    tile-aligned problem (the ragged GEMM extended by extra rows), dropout mask included; fused column sums count the
+    shared rows once."""
+    N, K = (768, 768) if mode == 0 else (512, 256)
+    g = torch.Generator(device="cuda").manual_seed(24)
+    tile = {8: 256, 9: 224, 10: 192, 0: 256}[mode]
+    Mp = (M + tile - 1) // tile * tile                                 # the aligned problem the ragged one is a prefix of
+    a = bf(torch.randn(Mp, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) * 0.1)
+    bias = bf(torch.randn(N, device="cuda", generator=g))
+    res = bf(torch.randn(Mp, N, device="cuda", generator=g))
+    aux = bf(torch.randn(Mp, N, device="cuda", generator=g))
+    variants = [dict(bias=bias, residual=res), dict(bias=bias, residual=res, dropout_p=0.1, dropout_seed=77),
+                dict(bias=bias, act=ops.ACT_RELU, dropout_p=0.1, dropout_seed=5),
+                dict(aux_in=aux, dact=ops.ACT_RELU, dact_scale=1.0 / 0.9), dict()]
+    for kw in variants:
+        cut = {k: (v[:M] if k in ("residual", "aux_in") else v) for k, v in kw.items()}
+        ops.KERNEL_LOG = []
+        got = ops.gemm(a[:M], w, force_generic=mode, **cut)
+        ran, ops.KERNEL_LOG = ops.KERNEL_LOG, None
+        assert ran[0].startswith("gemm8p_kernel<"), ran
+        want = ops.gemm(a[:M], w, force_generic=1, **cut)
+        assert (got.float() - want.float()).abs().max() <= 2.0 ** -6 * want.float().abs().max(), kw
+        assert (got == want).float().mean().item() > 0.98, kw
+        full = ops.gemm(a, w, force_generic=mode if mode else 8, **kw)          # aligned: no overlapping tile
+        assert torch.equal(got, full[:M]), kw
+    # fused column sums (DACT | CSUM) over a ragged M: exact up to the usual rounding, bit-reproducible
+    kw = dict(aux_in=aux[:M], dact=ops.ACT_RELU, dact_scale=1.0 / 0.9)
+    c, cs = ops.gemm(a[:M], w, colsum=True, force_generic=mode, **kw)
+    exact = ((a[:M].float() @ w.float().t()) * (aux[:M].float() > 0) / 0.9).sum(0)
+    tol = 4.0 * math.sqrt(M) * 2.0 ** -9 * c.float().pow(2).mean().sqrt()
+    assert (cs - exact).abs().max() <= tol
+    assert torch.equal(cs, ops.gemm(a[:M], w, colsum=True, force_generic=mode, **kw)[1])
+    # the activation bit mask written / read over a ragged M
+    bits = torch.zeros((M, N // 8), device="cuda", dtype=torch.uint8)
+    h = ops.gemm(a[:M], w, bias=bias, act=ops.ACT_RELU, actmask=bits, force_generic=mode)
+    packed = ((h.float() > 0).view(M, N // 8, 8).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(-1)
+    assert torch.equal(bits, packed.to(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 768, 19600), (256, 512, 1024 + 72), (768, 2304, 49000)])
+def test_gemm_weight_gradient_ragged_k(ops, M, N, K):
+    """dW = dY^T X when the token rows are not a multiple of 128 (batch 100: k = 19 600): the 8-phase weight-gradient
+    kernel on the largest multiple of 128 + one more slab for the rest, against fp32 math, bit-reproducible."""
+    g = torch.Generator(device="cuda").manual_seed(32)
+    a = bf(torch.randn(K, M, device="cuda", generator=g))
+    b = bf(torch.randn(K, N, device="cuda", generator=g))
+    ops.KERNEL_LOG = []
+    c = ops.gemm(a, b, a_kmajor=True, b_kmajor=True)
+    ran, ops.KERNEL_LOG = ops.KERNEL_LOG, None
+    assert ran == ["gemm8p_km_kernel"], ran
+    close(c, a.float().t() @ b.float())
+    assert torch.equal(c, ops.gemm(a, b, a_kmajor=True, b_kmajor=True))
+    # the tail rows matter: zeroing them changes the (fp32) result by exactly their contribution
+    a0 = a.clone()
+    a0[K // 128 * 128:] = 0
+    c32 = ops.gemm(a, b, a_kmajor=True, b_kmajor=True, out_f32=True)
+    c0 = ops.gemm(a0, b, a_kmajor=True, b_kmajor=True, out_f32=True)
+    tail = a[K // 128 * 128:].float().t() @ b[K // 128 * 128:].float()
+    close(c32 - c0, tail, rel=1 / 64, abs_scale=1 / 64)
+
+
 def test_gemm_persistent_kernel_is_the_automatic_choice_and_deterministic(ops):
     M, N, K = 256 * 9, 768, 768
     g = torch.Generator(device="cuda").manual_seed(23)
