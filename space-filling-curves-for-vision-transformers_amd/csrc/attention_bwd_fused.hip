@@ -46,7 +46,7 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 __device__ __forceinline__ void dma_rows(char *img, const uint16_t *__restrict__ src, int ld, int N, int npad, int tid) {
     for (int p = tid; p < npad * 8; p += FT) {
         const int row = p >> 3, cs = p & 7;
-        const int c = cs ^ ((row >> 1) & 7);
+        const int c = cs ^ kc_swz(row);
         const uint16_t *g = src + size_t(min(row, N - 1)) * ld + c * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(img + p * 16), 16, 0, 0);
     }
@@ -68,8 +68,10 @@ __device__ __forceinline__ bf16x8 ds_tr_frag(const char *slot, int key0, int lan
 // NFC: number of 16-row fragments at compile time (0 = from N); DROP: dropout on the probabilities (compile-time: a
 // runtime flag put a branch around every hash, each one a scheduling barrier between the MFMAs).
 template <int NFC, bool DROP>
-__global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_attn_args a, int npad) {
+__global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_attn_args a, int npad, int stag_round, int stag_per, int stag_ticks) {
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    stagger_start(stag_round, stag_per, stag_ticks);
     char *qimg = smem, *doimg = smem + npad * 128, *kimg = smem + 2 * npad * 128, *dsb = smem + 3 * npad * 128;
     float *lse_s = reinterpret_cast<float *>(dsb + 2 * npad * 64), *del_s = lse_s + npad;
     uint32_t *rkey_s = reinterpret_cast<uint32_t *>(del_s + npad);   // dropout row key of every query
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     u32x4 opiece[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        const int p = tid + FT * i, row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+        const int p = tid + FT * i, row = p >> 3, c = (p & 7) ^ kc_swz(row);
         opiece[i] = u32x4{0u, 0u, 0u, 0u};
         if (row < N) opiece[i] = *reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(a.out) + (size_t(b) * N + row) * D + h * HD + c * 8);
     }
@@ -184,11 +186,8 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
                 for (int r = 0; r < 4; r++) {
                     const float pv = fast_exp2(s[r] * c2 - lse4[r]);
                     float keep = 1.f;                                 // 1 / (1 - p) where the element is kept, else 0
-                    if (DROP) {
-                        bool k0b, k1b;
-                        drop_keep2(rk4[r], uint32_t(key >> 1), dth, k0b, k1b);
-                        keep = ((key & 1) ? k1b : k0b) ? dsc : 0.f;
-                    }
+                    if (DROP)     // drop_keep2's flag of this lane's key: the 16-bit half (key & 1) of the pair hash, one v_bfe_u32
+                        keep = __builtin_amdgcn_ubfe(drop_pair_hash(rk4[r], uint32_t(key >> 1)), uint32_t(key & 1) * 16u, 16u) >= dth ? dsc : 0.f;
                     p[t][r] = pv * keep;
                     ds[t][r] = pv * (dp[r] * keep - del4[r]);             // x scale at the stores of dK and dQ
                 }
@@ -328,27 +327,31 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
 constexpr int FUSED_MAX_N = 32 * FMAXC;
 constexpr int FUSED_MAX_LDS = FUSED_MAX_N * FUSED_ROW_BYTES + FUSED_EXTRA;
 
+template <int NFC, bool DROP>
+int launch_fused(const sfcvit_attn_args &a, int npad, size_t lds, int round, int per, int ticks, hipStream_t s) {
+    if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<NFC, DROP>), FUSED_MAX_LDS, "attention_bwd_fused attribute")) return rc;
+    hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<NFC, DROP>), dim3(a.H, a.B), dim3(FT), lds, s, a, npad, round, per, ticks);
+    return check_launch("attention_bwd_fused");
+}
+
 }  // namespace
 
 // -1: not eligible (the caller falls back to the two-kernel form); else a status.
 int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s) {
     if (a.hd != HD || a.N > FUSED_MAX_N) return -1;
-    for (const void *k : {reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<0, false>),
-                          reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<0, true>),
-                          reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<13, false>),
-                          reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<13, true>)})
-        if (int rc = raise_lds_limit(k, FUSED_MAX_LDS, "attention_bwd_fused attribute")) return rc;
     const int npad = (a.N + 31) / 32 * 32;
-    const size_t lds = size_t(std::max(npad * FUSED_ROW_BYTES, FUSED_POST_BYTES)) + FUSED_EXTRA;
     const bool nf13 = (a.N + 15) / 16 == 13, drop = a.dropout_p > 0.f;
-    const dim3 grid(a.H, a.B), block(FT);
+    const size_t lds = size_t(std::max(npad * FUSED_ROW_BYTES, FUSED_POST_BYTES)) + FUSED_EXTRA;
+    // Start-up stagger (attention_common.h): one workgroup per CU, every one of them opens with a 117 KiB load burst and they
+    // all take the same time, so launched together they stay in lockstep.  Two slots 4.5 us apart: 270.8 -> 257.1 us at
+    // ViT-B / 256 (3 or 4 slots, 2-8 us: 255.6-258.6).  SFCVIT_ATTN_STAGGER_BWD = "slots,ticks" (10 ns) overrides; "1,0" = off.
+    int slots = 2, ticks = 450;
+    if (const char *e = getenv("SFCVIT_ATTN_STAGGER_BWD")) sscanf(e, "%d,%d", &slots, &ticks);
+    if (slots < 1) slots = 1;
+    const int round = 256, per = (round + slots - 1) / slots;
     note_attn_kernel("attn_seq_bwd_fused_kernel<%d, %s>", nf13 ? 13 : 0, drop ? "true" : "false");
-    if (nf13 && drop) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<13, true>), grid, block, lds, s, a, npad);
-    else if (nf13) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<13, false>), grid, block, lds, s, a, npad);
-    else if (drop) hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<0, true>), grid, block, lds, s, a, npad);
-    else hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<0, false>), grid, block, lds, s, a, npad);
-    return check_launch("attention_bwd_fused");
+    if (nf13) return drop ? launch_fused<13, true>(a, npad, lds, round, per, ticks, s) : launch_fused<13, false>(a, npad, lds, round, per, ticks, s);
+    return drop ? launch_fused<0, true>(a, npad, lds, round, per, ticks, s) : launch_fused<0, false>(a, npad, lds, round, per, ticks, s);
 }
 
 }  // namespace sfcvit
-

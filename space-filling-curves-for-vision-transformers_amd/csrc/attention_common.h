@@ -106,6 +106,20 @@ __device__ __forceinline__ bf16x8 tr_frag_at(const char *img, int r_lo, int lane
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Start-up stagger of the whole-sequence kernels.  Their workgroups all take the same time and all begin with a load
+// burst (K / V or Q / dO / K images of one (batch, head)): launched together they stay in lockstep for the whole kernel
+// -- every round of workgroups hits HBM at once (~11 B/clock per CU) and then leaves it idle while it computes.  The
+// workgroups of the FIRST round (linear id < first_round) therefore start `slot * ticks` late (ticks of the 100 MHz
+// s_memrealtime clock), slot = id / per_slot: after that the rounds of the slots interleave load and compute phases
+// for the rest of the kernel.  ticks == 0: off.
+__device__ __forceinline__ void stagger_start(int first_round, int per_slot, int ticks) {
+    if (ticks <= 0) return;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lin >= first_round) return;
+    const uint64_t until = __builtin_amdgcn_s_memrealtime() + uint64_t(lin / per_slot) * uint64_t(ticks);
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
+}
+
 // reduce over the four 16-lane groups (same lane&15)
 __device__ __forceinline__ float group_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));

@@ -32,7 +32,7 @@ template <bool VT>
 __device__ __forceinline__ void dma_seq(char *img, const uint16_t *__restrict__ src, int ld, int N, int npad, int tid) {
     for (int p = tid; p < npad * 8; p += THREADS) {     // npad % 32 == 16: the last trip is half a workgroup
         const int row = p >> 3, cs = p & 7;
-        const int c = VT ? ((((cs >> 1) ^ ((row >> 1) & 3)) << 1) | (cs & 1)) : (cs ^ ((row >> 1) & 7));
+        const int c = cs ^ kc_swz(row);        // "kc" and "vt" images share one swizzle now (device_common.h)
         const uint16_t *g = src + size_t(min(row, N - 1)) * ld + c * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(img + p * 16), 16, 0, 0);
     }
@@ -54,7 +54,13 @@ constexpr int MAXOWN = MAXF / WAVES;   // fragments a wave owns at most (4)
 // per-fragment `kf < nf` tests of the fully unrolled score row and the chunk loops fold away -- for the generic version
 // hipcc emits ~250 branches around the forward kernel's MFMAs, each one a scheduling barrier.  ViT-B/16 @ 224
 // (N = 196) runs the 13-fragment instances.
-template <int NFC>
+// DROP = dropout on the probabilities, at compile time.  Measured and not kept (round 3, ViT-B / 256, same process):
+// seven waves per workgroup, two fragments per wave, two workgroups per CU -- 13 fragments then fall 2/2/2/2/2/2/1
+// instead of 4/3/3/3 -- 109.7 vs 90.9 us; a start-up stagger of the three workgroups of a CU: 91-102 vs 90.5 us; handing the
+// keep flags to the backward pass as a bit matrix (the compare's lane masks collected by v_writelane, one 8-byte store per
+// lane and fragment; the one-pass backward then reads a word and extracts bits instead of hashing): forward 87.0 -> 98.5 us,
+// backward 252.0 -> 242.0 us -- a wash, removed again.
+template <int NFC, bool DROP>
 __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_attn_args a, int npad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *kimg = smem, *vimg = smem + npad * 128;
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_a
     __syncthreads();                                     // LDS-DMA pending: hipcc drains vmcnt(0) here
     const float c2 = a.scale * 1.4426950408889634f;     // exp(x * scale) = exp2(x * c2)
     const LaneOff lo = lane_offsets(lane);
-    const bool drop = a.dropout_p > 0.f;
+    constexpr bool drop = DROP;
     const uint32_t dth = drop_thresh(a.dropout_p);
     const float dsc = 1.f / (1.f - a.dropout_p);
 
@@ -121,11 +127,16 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_a
                     s[kf][r] = fast_exp2(s[kf][r] * c2 - mc);
                     l += s[kf][r];
                 }
-                if (drop) {
-                    float keep[4];
-                    drop_keep4(drk, 16 * kf + 4 * (lane >> 4), dth, dsc, keep);
+                if (drop) {                                          // 1 / (1 - p) is applied with 1 / l at the store
+                    bool k[4];
+                    drop_keep2(drk, uint32_t(8 * kf + 2 * (lane >> 4)), dth, k[0], k[1]);
+                    drop_keep2(drk, uint32_t(8 * kf + 2 * (lane >> 4)) + 1, dth, k[2], k[3]);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) s[kf][r] *= keep[r];
+                    for (int r = 0; r < 4; r++) {
+                        s[kf][r] = k[r] ? s[kf][r] : 0.f;
+                        asm volatile("" ::"v"(s[kf][r]));     // pins the select here: without an anchor per element hipcc hoists
+                                                              // all 52 hashes of the row ahead of their uses and spills
+                    }
                 }
             }
         l = group_sum(l);
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_a
                 }
         }
         mfma_fence();
-        store_rows(out, D, q, q < N, acc, 1.f / l, lane);
+        store_rows(out, D, q, q < N, acc, (drop ? dsc : 1.f) / l, lane);
         if (q < N && lane < 16) a.lse[(size_t(b) * a.H + h) * N + q] = mx * a.scale + __logf(l);
     }
 }
@@ -331,8 +342,9 @@ constexpr int SEQ_MAX_N = 256;
 constexpr int SEQ_MAX_LDS = 2 * SEQ_MAX_N * 128 + 3 * SEQ_MAX_N * 4;
 
 int set_lds_limit() {
-    for (const void *k : {reinterpret_cast<const void *>(&attn_seq_fwd_kernel<0>), reinterpret_cast<const void *>(&attn_seq_bwd_kv_kernel<0>),
-                          reinterpret_cast<const void *>(&attn_seq_bwd_q_kernel<0>), reinterpret_cast<const void *>(&attn_seq_fwd_kernel<13>),
+    for (const void *k : {reinterpret_cast<const void *>(&attn_seq_fwd_kernel<0, false>), reinterpret_cast<const void *>(&attn_seq_fwd_kernel<0, true>),
+                          reinterpret_cast<const void *>(&attn_seq_fwd_kernel<13, false>), reinterpret_cast<const void *>(&attn_seq_fwd_kernel<13, true>),
+                          reinterpret_cast<const void *>(&attn_seq_bwd_kv_kernel<0>), reinterpret_cast<const void *>(&attn_seq_bwd_q_kernel<0>),
                           reinterpret_cast<const void *>(&attn_seq_bwd_kv_kernel<13>), reinterpret_cast<const void *>(&attn_seq_bwd_q_kernel<13>)})
         if (int rc = raise_lds_limit(k, SEQ_MAX_LDS, "attention_seq attribute")) return rc;
     return SFCVIT_OK;
@@ -344,9 +356,15 @@ int attn_seq_fwd(const sfcvit_attn_args &a, hipStream_t s) {
     if (a.N > SEQ_MAX_N) return -1;
     if (int rc = set_lds_limit()) return rc;
     const int npad = (a.N + 15) / 16 * 16;
-    note_attn_kernel("attn_seq_fwd_kernel<%d>", (a.N + 15) / 16 == 13 ? 13 : 0);
-    if ((a.N + 15) / 16 == 13) hipLaunchKernelGGL(attn_seq_fwd_kernel<13>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128), s, a, npad);
-    else hipLaunchKernelGGL(attn_seq_fwd_kernel<0>, dim3(a.H, a.B), dim3(THREADS), size_t(2 * npad * 128), s, a, npad);
+    const int nf = (a.N + 15) / 16;
+    const bool drop = a.dropout_p > 0.f;
+    note_attn_kernel("attn_seq_fwd_kernel<%d, %s>", nf == 13 ? 13 : 0, drop ? "true" : "false");
+    const dim3 grid(a.H, a.B), block(THREADS);
+    const size_t lds = size_t(2 * npad * 128);
+    if (nf == 13 && drop) hipLaunchKernelGGL((attn_seq_fwd_kernel<13, true>), grid, block, lds, s, a, npad);
+    else if (nf == 13) hipLaunchKernelGGL((attn_seq_fwd_kernel<13, false>), grid, block, lds, s, a, npad);
+    else if (drop) hipLaunchKernelGGL((attn_seq_fwd_kernel<0, true>), grid, block, lds, s, a, npad);
+    else hipLaunchKernelGGL((attn_seq_fwd_kernel<0, false>), grid, block, lds, s, a, npad);
     return check_launch("attention_seq_fwd");
 }
 

@@ -26,7 +26,7 @@ template <bool VT>
 __device__ __forceinline__ void dma_slice(char *img, const uint16_t *__restrict__ src, int ld, int N, int npad, int tid) {
     for (int p = tid; p < npad * 8; p += THREADS) {
         const int row = p >> 3, cs = p & 7;
-        const int c = VT ? ((((cs >> 1) ^ ((row >> 1) & 3)) << 1) | (cs & 1)) : (cs ^ ((row >> 1) & 7));
+        const int c = cs ^ kc_swz(row);        // "kc" and "vt" images share one swizzle now (device_common.h)
         const uint16_t *g = src + size_t(min(row, N - 1)) * ld + c * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(img + p * 16), 16, 0, 0);
     }

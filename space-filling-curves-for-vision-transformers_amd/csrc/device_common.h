@@ -37,10 +37,14 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 
 // ---- LDS images used by the MFMA kernels ------------------------------------
-// "kc" image: [rows][64] bf16 (128-B rows), k contiguous.  16-B chunk index is
-// XOR-ed with (row >> 1) & 7: conflict-free for ds_write_b128 staging and for the
-// ds_read_b128 fragment reads below (tools/lds_conflicts.py).
-__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// "kc" image: [rows][64] bf16 (128-B rows), k contiguous.  16-B chunk index is XOR-ed with kc_swz(row) =
+// 2 ((row >> 1) & 3): conflict-free for ds_write_b128 staging, for the ds_read_b128 fragment reads below AND for the
+// transposed ds_read_b64_tr_b16 reads of the same image (attention backward reads Q, dO and K both ways)
+// (tools/lds_conflicts.py).  Rounds 1-2 XOR-ed with (row >> 1) & 7: the same for the row reads, but every transposed
+// read took two LDS passes (rows r and r + 2 of a 4-row block on the same banks) -- 36 % of the LDS-active cycles of the
+// one-pass attention backward were bank conflicts (profiles/r2/README.md).
+__device__ __forceinline__ int kc_swz(int row) { return ((row >> 1) & 3) << 1; }
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ kc_swz(row)) << 4); }
 
 // Fragment of 16 rows x 32 k from a kc image: lane holds row (lane&15), k = 8*(lane>>4)+j.
 __device__ __forceinline__ bf16x8 kc_frag(const char *img, int row0, int kk, int lane) {

@@ -170,7 +170,8 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
 }
 
 
-template <int NI, int MASK>
+// P2 = the two-phase schedule of a k-tile (see ktile2 below): 4 barriers per k-tile instead of 8.
+template <int NI, int MASK, bool P2 = false>
 __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, unsigned *__restrict__ counters) {
     constexpr int BM = 32 * NI, GR = 16 * NI;               // tile rows, rows per wave group
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: ring of 2 x [A0 | A1 | B0 | B1]
@@ -458,10 +459,16 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
     stage_b(cb, 0, 0); stage_a(ca, 0, 0); stage_a(ca, 0, 1); stage_b(cb, 0, 1);
     advance(ca, true);
     advance(cb, false);
-    stage_b(cb, 1, 0); stage_a(ca, 1, 0); stage_a(ca, 1, 1); stage_b(cb, 1, 1);
-    advance(ca, true);
-    advance(cb, false);
-    wait_vm<8>();                             // k-tile 0
+    if (P2) {                                 // two-phase schedule: A1 of k-tile 1 is staged by the loop's first load section
+        stage_b(cb, 1, 0); stage_a(ca, 1, 0); stage_b(cb, 1, 1);
+        advance(cb, false);
+        wait_vm<6>();                         // k-tile 0
+    } else {
+        stage_b(cb, 1, 0); stage_a(ca, 1, 0); stage_a(ca, 1, 1); stage_b(cb, 1, 1);
+        advance(ca, true);
+        advance(cb, false);
+        wait_vm<8>();                         // k-tile 0
+    }
     bar();
     if (wr == 1) bar();                       // wave group 1 runs one barrier behind group 0
     zero_acc();
@@ -530,12 +537,66 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
             stage_next(buf);
         }
     };
+    // Two-phase schedule of a k-tile (P2): the same ring, the same half-tiles, HALF the barriers.
+    //     section   reads (LDS)     LDS-DMA issued                         MFMA (rows x cols)    counted wait before the barrier
+    //     X load    A0, B0, B1      A1 of k-tile g+1                       -                     vmcnt(8): A1 of k-tile g
+    //     X mma     -               -                                      a0 x b0, a0 x b1      -
+    //     Y load    A1              A0, B0, B1 of k-tile g+2 (this buffer)  -                     vmcnt(8): A0, B0, B1 of k-tile g+1
+    //     Y mma     -               -                                      a1 x b0, a1 x b1      -
+    // A load section ends with lgkmcnt(0) BEFORE its barrier (the other group's 24-32 MFMAs cover the LDS latency), so a
+    // half-tile may be overwritten from the section after its (second) read on: A0 / B0 / B1 of k-tile g are read in the
+    // X sections (barriers 0 and 1 of the k-tile, the two groups one barrier apart) and restaged in the Y sections
+    // (barriers 2 and 3); A1 is read in the Y sections and restaged in the next k-tile's X sections.  Every DMA has one
+    // whole k-tile between issue and the wait that retires it, as in the four-phase schedule.  At a tile boundary
+    // everything the next k-tile's two waits retire was issued BEFORE the epilogue's stores: vmcnt(8 + NSTORE).
+    auto ktile2 = [&](int buf, bool first, bool last) __attribute__((always_inline)) {
+        // X: a0 x (b0, b1)
+        read_b(fb0, buf, 0);
+        read_b(fb1, buf, 1);
+        read_a0(buf);
+        stage_a(ca, buf ^ 1, 1);
+        advance(ca, true);
+        __builtin_amdgcn_sched_barrier(0);
+        if (first && t > 0) wait_vm<8 + NSTORE>();
+        else wait_vm<8>();
+        wait_lgkm<0>();
+        bar();
+        mma0(fb0, 0);
+        mma0(fb1, 1);
+        if (first) set_next(t + 1);           // entry t + 1 was published an epilogue and several barriers ago
+        bar();
+        // Y: a1 x (b0, b1)
+        read_a1(buf);
+        stage_b(cb, buf, 0);
+        stage_a(ca, buf, 0);
+        stage_b(cb, buf, 1);
+        advance(cb, false);
+        __builtin_amdgcn_sched_barrier(0);
+        if (first && t > 0) wait_vm<8 + NSTORE>();
+        else wait_vm<8>();
+        wait_lgkm<0>();
+        bar();
+        mma1(fb0, 0);
+        mma1(fb1, 1);
+        if (last) {
+            if (wr == 0) {
+                bar();
+                draw();
+            }
+            epilogue();
+            if (wr == 1) bar();
+        } else {
+            bar();
+        }
+    };
     int kt = 0;
     for (;;) {
-        ktile(0, kt == 0, false);
+        if (P2) ktile2(0, kt == 0, false);
+        else ktile(0, kt == 0, false);
         kt += 2;
         const bool last = kt == KT;
-        ktile(1, false, last);
+        if (P2) ktile2(1, false, last);
+        else ktile(1, false, last);
         if (last) {
             kt = 0;
             t++;
@@ -561,6 +622,7 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
 // workgroups, each with one k-range, writing its fp32 partial tile to slab z of the workspace; sfcvit_gemm's ordered
 // split-K reduction sums the slabs (deterministic, no atomics).
 // ----------------------------------------------------------------------------------------------------------------
+template <bool P2>
 __global__ __launch_bounds__(T) void gemm8p_km_kernel(const sfcvit_gemm_args g, int kt_per_split, int nsplits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3;
@@ -668,50 +730,96 @@ __global__ __launch_bounds__(T) void gemm8p_km_kernel(const sfcvit_gemm_args g, 
         __builtin_amdgcn_s_setprio(0);
     };
 
-    stage_b(0, 0); stage_a(0, 0); stage_a(0, 1); stage_b(0, 1);
-    advance_a();
-    advance_b();
-    stage_b(1, 0); stage_a(1, 0);
-    wait_vm<4>();
-    bar();
-    if (wr == 1) bar();
-    // same schedule as gemm8p_kernel (table at the top of the file); the half-tiles are contiguous 128-column blocks
-    // here, and a wave takes its a0 / a1 (b0 / b1) fragments from the first / second of them
-    auto ktile = [&](int buf) __attribute__((always_inline)) {
-        read_b(fb0, 0);
-        read_a2(fa0, 0, 0);
-        read_a2(fa0, 0, 2);
-        stage_a(buf ^ 1, 1);
+    if (P2) {
+        // two-phase schedule (see gemm8p_kernel's ktile2): X = {reads A0, B0, B1; stages A1 of k-tile g+1}, a0 x (b0, b1);
+        // Y = {reads A1; stages A0, B0, B1 of k-tile g+2 into this buffer}, a1 x (b0, b1); every load section ends with
+        // lgkmcnt(0) and vmcnt(8) before its barrier.  One A cursor serves both halves: A0 of k-tile g+2 (Y of k-tile g) is
+        // staged before A1 of k-tile g+2 (X of k-tile g+1), then the cursor advances.
+        stage_b(0, 0); stage_a(0, 0); stage_a(0, 1); stage_b(0, 1);        // k-tile 0 in full
         advance_a();
-        bar();
-        wait_lgkm<0>();
-        mma(fa0, fb0, 0, 0);
-        bar();
-        read_a2(fa1, 1, 0);
-        read_a2(fa1, 1, 2);
-        stage_b(buf ^ 1, 1);
         advance_b();
+        stage_b(1, 0); stage_a(1, 0); stage_b(1, 1);                       // A0, B0, B1 of k-tile 1
+        advance_b();
+        wait_vm<6>();
         bar();
-        wait_lgkm<0>();
-        mma(fa1, fb0, 1, 0);
-        bar();
-        read_b(fb1, 1);
-        stage_b(buf, 0);
-        bar();
-        wait_lgkm<0>();
-        mma(fa1, fb1, 1, 1);
-        bar();
-        stage_a(buf, 0);
+        if (wr == 1) bar();
+        auto ktile2 = [&](int buf) __attribute__((always_inline)) {
+            read_b(fb0, 0);
+            read_b(fb1, 1);
+            read_a2(fa0, 0, 0);
+            read_a2(fa0, 0, 2);
+            stage_a(buf ^ 1, 1);
+            advance_a();
+            wait_vm<8>();
+            wait_lgkm<0>();
+            bar();
+            mma(fa0, fb0, 0, 0);
+            mma(fa0, fb1, 0, 1);
+            bar();
+            read_a2(fa1, 1, 0);
+            read_a2(fa1, 1, 2);
+            stage_b(buf, 0);
+            stage_a(buf, 0);
+            stage_b(buf, 1);
+            advance_b();
+            wait_vm<8>();
+            wait_lgkm<0>();
+            bar();
+            mma(fa1, fb0, 1, 0);
+            mma(fa1, fb1, 1, 1);
+            bar();
+            flip();
+        };
+        for (int k = 0; k < nkt; k += 2) {
+            ktile2(0);
+            ktile2(1);
+        }
+    } else {
+        stage_b(0, 0); stage_a(0, 0); stage_a(0, 1); stage_b(0, 1);
+        advance_a();
+        advance_b();
+        stage_b(1, 0); stage_a(1, 0);
         wait_vm<4>();
         bar();
-        mma(fa0, fb1, 0, 1);
-        bar();
-        flip();
-    };
-    for (int k = 0; k < nkt; k += 2) {
-        ktile(0);
-        ktile(1);
-    }
+        if (wr == 1) bar();
+        // same schedule as gemm8p_kernel (table at the top of the file); the half-tiles are contiguous 128-column blocks
+        // here, and a wave takes its a0 / a1 (b0 / b1) fragments from the first / second of them
+        auto ktile = [&](int buf) __attribute__((always_inline)) {
+            read_b(fb0, 0);
+            read_a2(fa0, 0, 0);
+            read_a2(fa0, 0, 2);
+            stage_a(buf ^ 1, 1);
+            advance_a();
+            bar();
+            wait_lgkm<0>();
+            mma(fa0, fb0, 0, 0);
+            bar();
+            read_a2(fa1, 1, 0);
+            read_a2(fa1, 1, 2);
+            stage_b(buf ^ 1, 1);
+            advance_b();
+            bar();
+            wait_lgkm<0>();
+            mma(fa1, fb0, 1, 0);
+            bar();
+            read_b(fb1, 1);
+            stage_b(buf, 0);
+            bar();
+            wait_lgkm<0>();
+            mma(fa1, fb1, 1, 1);
+            bar();
+            stage_a(buf, 0);
+            wait_vm<4>();
+            bar();
+            mma(fa0, fb1, 0, 1);
+            bar();
+            flip();
+        };
+        for (int k = 0; k < nkt; k += 2) {
+            ktile(0);
+            ktile(1);
+        }
+}
     if (wr == 0) bar();
     wait_vm<0>();
     mfma_fence();
@@ -780,10 +888,19 @@ unsigned *queue_counters(hipStream_t s) {
 template <int NI, int MASK>
 int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
     const int LDS_TOTAL = LDS_BIAS + (a.bias ? a.N * 2 : 0);
-    if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>), LDS_MAX, "gemm8p attribute")) return rc;
     unsigned *counters = queue_counters(s);
     if (!counters) return fail(SFCVIT_ELAUNCH, "gemm8p: could not allocate the tile-queue counters");
     note_gemm_kernel(1, NI, MASK);
+    // the two-phase k-tile schedule is the default; SFCVIT_GEMM_2PHASE=0 selects the four-phase one (A/B in one process)
+    const char *e = getenv("SFCVIT_GEMM_2PHASE");
+    if (!(e && e[0] == '0')) {
+        if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK, true>), LDS_MAX, "gemm8p attribute")) return rc;
+        hipLaunchKernelGGL((gemm8p_kernel<NI, MASK, true>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters);
+        const int rc = check_launch("gemm8p");
+        if (rc) (void)hipMemsetAsync(counters, 0, SLOT_UINTS * sizeof(unsigned), s);
+        return rc;
+    }
+    if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>), LDS_MAX, "gemm8p attribute")) return rc;
     hipLaunchKernelGGL((gemm8p_kernel<NI, MASK>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters);
     const int rc = check_launch("gemm8p");
     if (rc) (void)hipMemsetAsync(counters, 0, SLOT_UINTS * sizeof(unsigned), s);   // a launch that did not run leaves no debt
@@ -818,7 +935,7 @@ int launch_mask(const sfcvit_gemm_args &a, int mask, int grid, hipStream_t s) {
 int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_used, int *k_done, hipStream_t s) {
     using namespace p8;
     if (!a.a_kmajor || !a.b_kmajor || splits_req < 2) return -1;
-    if (a.M % 256 || a.N % 256 || a.K < 1024 || a.lda % 8 || a.ldb % 8) return -1;
+    if (a.M % 256 || a.N % 256 || a.K < 256 || a.lda % 8 || a.ldb % 8) return -1;
     const int cus = device_cus();
     if (!cus) return -1;
     const int Kb = a.K / 128 * 128, tail = a.K - Kb;
@@ -831,11 +948,17 @@ int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_us
     int kps = ((KT + splits - 1) / splits + 1) / 2 * 2;           // k-tiles per split, even
     splits = (KT + kps - 1) / kps;
     if (splits < 2) return -1;
-    if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_km_kernel), LDS_BYTES, "gemm8p_km attribute")) return rc;
     note_gemm_kernel(2);
     sfcvit_gemm_args body = a;
     body.K = Kb;
-    hipLaunchKernelGGL(gemm8p_km_kernel, dim3((tiles * splits + 7) / 8 * 8), dim3(T), LDS_BYTES, s, body, kps, splits);
+    const char *e = getenv("SFCVIT_GEMM_2PHASE");              // "0": the four-phase k-tile schedule (A/B in one process)
+    if (e && e[0] == '0') {
+        if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_km_kernel<false>), LDS_BYTES, "gemm8p_km attribute")) return rc;
+        hipLaunchKernelGGL(gemm8p_km_kernel<false>, dim3((tiles * splits + 7) / 8 * 8), dim3(T), LDS_BYTES, s, body, kps, splits);
+    } else {
+        if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_km_kernel<true>), LDS_BYTES, "gemm8p_km attribute")) return rc;
+        hipLaunchKernelGGL(gemm8p_km_kernel<true>, dim3((tiles * splits + 7) / 8 * 8), dim3(T), LDS_BYTES, s, body, kps, splits);
+    }
     *splits_used = splits;
     *k_done = Kb;
     return check_launch("gemm8p_km");

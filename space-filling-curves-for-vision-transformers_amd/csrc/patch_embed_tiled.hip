@@ -97,7 +97,7 @@ __global__ __launch_bounds__(PT) void pe2_fwd_kernel(const void *__restrict__ x,
     // 4 MiB L2: 403 MB memory-side fetch for 154 MB of image), not by latency; the generic kernel took 338 us + a 32 us cast.
     const int arow = tid >> 2, aseg = tid & 3;
     const long long asrc = rows[arow].src + aseg * sstep;
-    const int aw0 = arow * 128 + (((2 * aseg) ^ ((arow >> 1) & 7)) << 4), aw1 = arow * 128 + (((2 * aseg + 1) ^ ((arow >> 1) & 7)) << 4);
+    const int aw0 = kc_off(arow, 2 * aseg), aw1 = kc_off(arow, 2 * aseg + 1);
     const uint16_t *wbase = wp + (size_t(cls) * D + size_t(ct) * TN) * K;
     constexpr int NA = XBF16 ? 2 : 4;
     struct Stage { u32x4 a[NA]; u32x4 b[4]; };
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(PT) void pe2_fwd_kernel(const void *__restrict__ x,
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int p = tid + PT * i, row = p >> 3, cs = p & 7;
-            *reinterpret_cast<u32x4 *>(bbuf + buf * B_BYTES + row * 128 + ((cs ^ ((row >> 1) & 7)) << 4)) = st.b[i];
+            *reinterpret_cast<u32x4 *>(bbuf + buf * B_BYTES + kc_off(row, cs)) = st.b[i];
         }
     };
 

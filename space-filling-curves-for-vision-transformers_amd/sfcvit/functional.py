@@ -34,12 +34,15 @@ def _like(g, ref):
     return g if g.dtype == ref.dtype else g.to(ref.dtype)
 
 
+_SLOTS_OFF = False     # sfcvit.library: inside a traced custom op gradients must be fresh tensors, never views of the flat buffer
+
+
 def _slot(p):
     """A fresh view of parameter `p`'s place in its optimizer's flat gradient buffer (FlatGradBuffer.slots), or None.
     Kernels write the gradient there directly and return the view: autograd, finding p.grad unset, adopts it as
     p.grad without a copy -- no fp32 -> bf16 cast and no `p.grad += g` pass per parameter (146 + 106 tiny kernels per
     ViT-B step).  Only when p.grad is None: with an existing gradient autograd would add the view to itself."""
-    if p is None or not p.is_leaf or p.grad is not None:
+    if _SLOTS_OFF or p is None or not p.is_leaf or p.grad is not None:
         return None
     slot = getattr(p, "_sfcvit_slot", None)
     if slot is None:
@@ -125,9 +128,17 @@ class _PatchEmbed(Function):
         return None, None, dw.to(_BF16), (db.to(_BF16) if db is not None else None), None
 
 
+def _traced():
+    """Under torch.compile the blocks run as `sfcvit::` custom ops (sfcvit/library.py): one graph, no breaks."""
+    return torch.compiler.is_compiling()
+
+
 def patch_embed(x, pix, weight, bias, desc=None):
     """Fused curve gather + patchify + projection: x [B,C,H,W] (fp32 or bf16) -> [B,N,D] bf16.
     desc = ops.TileDesc of the pixel table (tokens are 16 x 16 tiles / 256-pixel strips) or None."""
+    if _traced():
+        from . import library
+        return library.patch_embed(x, pix, _bf(weight), _bf(bias), desc)
     return _PatchEmbed.apply(x, pix, _bf(weight), _bf(bias), desc)
 
 
@@ -346,6 +357,9 @@ class _Mixer(Function):
 
 
 def mixer_block(x, ln_w, ln_b, w1, b1, w2, b2, eps=1e-5):
+    if _traced():
+        from . import library
+        return library.mixer_block(_bf(x), _bf(ln_w), _bf(ln_b), _bf(w1), _bf(b1), _bf(w2), _bf(b2), eps)
     return _Mixer.apply(_bf(x), _bf(ln_w), _bf(ln_b), _bf(w1), _bf(b1), _bf(w2), _bf(b2), eps)
 
 
@@ -457,6 +471,9 @@ def encoder_layer(x, in_w, in_b, out_w, out_b, n1_w, n1_b, w1, b1, w2, b2, n2_w,
             args[2] = pad(args[2].reshape(3, n_heads, hd), (0, hp - hd)).reshape(3 * n_heads * hp)
         args[3] = pad(args[3].reshape(D, n_heads, hd), (0, hp - hd)).reshape(D, n_heads * hp)
         scale = 1.0 / math.sqrt(hd)
+    if _traced():
+        from . import library      # (dropout seeds are drawn inside the op: nothing data-dependent in the traced graph)
+        return library.encoder_layer(args, n_heads, eps, float(dropout_p), scale)
     seeds = tuple(ops.next_seed() for _ in range(4)) if dropout_p > 0 else (0, 0, 0, 0)
     return _EncoderLayer.apply(*args, n_heads, eps, float(dropout_p), seeds, scale)
 
@@ -511,6 +528,9 @@ class _Head(Function):
 
 
 def predictor_head(x, ln_w, ln_b, w_emb, w_seq, wc, bc, eps=1e-5, dropout_p=0.0):
+    if _traced():
+        from . import library
+        return library.predictor_head(_bf(x), _bf(ln_w), _bf(ln_b), _bf(w_emb), _c(_bf(w_seq)), _bf(wc), _bf(bc), eps, float(dropout_p))
     seed = ops.next_seed() if dropout_p > 0 else 0
     return _Head.apply(_bf(x), _bf(ln_w), _bf(ln_b), _bf(w_emb), _c(_bf(w_seq)), _bf(wc), _bf(bc), eps,
                        float(dropout_p), seed)
@@ -535,17 +555,20 @@ class _SoftCE(Function):
 
 def soft_target_cross_entropy(logits, targets):
     """-(targets * log_softmax(logits)).sum(-1).mean() with the gradient produced in the same pass."""
+    if _traced():
+        from . import library
+        return library.soft_ce(_bf(logits), targets)
     return _SoftCE.apply(_bf(logits), targets)
 
 
 # ----------------------------------------------------------------------------
-# torch.compile (main.py:284 wraps the model in torch.compile(mode="reduce-overhead")).  The blocks above are opaque to
-# Dynamo -- ctypes launches of the C ABI inside autograd.Functions that hand out views of the flat gradient buffer, which
-# a traced custom op may not alias -- so they are declared as such: Dynamo breaks the graph around each block and runs it
-# as written.  What "reduce-overhead" is after (no per-launch host cost) is delivered for the whole training step by
-# sfcvit.training.GraphedTrainStep instead of per compiled region.
+# torch.compile (main.py:284 wraps the model in torch.compile(mode="reduce-overhead")).  The blocks a VisionTransformer{,1D}
+# is made of -- patch_embed, mixer_block, encoder_layer, predictor_head, soft_target_cross_entropy -- are registered as
+# `sfcvit::` custom ops with fake kernels and autograd formulas (sfcvit/library.py) and take that path whenever Dynamo is
+# tracing: the model compiles into ONE graph and "reduce-overhead" replays it from a hipGraph.  The remaining pieces
+# (used by the hierarchical tokenizers, altvit and MultiLayerPredictor(n_layers > 2)) stay opaque: Dynamo breaks the graph
+# around each and runs it as written.
 # ----------------------------------------------------------------------------
-for _name in ("patch_embed", "hier_tokenizer", "linear", "layer_norm", "gelu", "attention", "mixer_block", "encoder_layer", "predictor_head",
-              "soft_target_cross_entropy"):
+for _name in ("hier_tokenizer", "linear", "layer_norm", "gelu", "attention"):
     globals()[_name] = torch.compiler.disable(globals()[_name], recursive=True)
 del _name

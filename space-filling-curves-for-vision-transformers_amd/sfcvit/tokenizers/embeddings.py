@@ -73,11 +73,27 @@ class _FusedTokenizer(BasePatchEmbedding):
             self._pix_key = key
         return self._pix
 
+    def _apply(self, fn, *args, **kwargs):
+        """`.to(device)` / `.cuda()`: build the device tables right away, so that a model that is moved and then wrapped in
+        torch.compile (the reference's order, main.py:252-284) never has to build them inside a traced forward."""
+        out = super()._apply(fn, *args, **kwargs)
+        dev = self.proj.weight.device
+        if dev.type == "cuda" and getattr(self, "_geom", None) is not None:
+            self._pix_table(dev)
+        return out
+
     def forward(self, x):
         img = self._geom[0]
         if x.dim() != 4 or x.shape[2] != img or x.shape[3] != img:
             raise ValueError(f"expected [B, C, {img}, {img}] input, got {tuple(x.shape)}")
-        pix = self._pix_table(x.device)
+        if torch.compiler.is_compiling():
+            # the cache key reads data_ptr() / _version, which Dynamo cannot trace: the tables exist (built by .to(device))
+            if self._pix is None or self._pix.device != x.device:
+                raise RuntimeError("tokenizer device tables are missing: move the model to the device (model.to(device)) "
+                                   "before wrapping it in torch.compile")
+            pix = self._pix
+        else:
+            pix = self._pix_table(x.device)
         return F.patch_embed(x, pix, self.proj.weight, self.proj.bias, self._desc)
 
 

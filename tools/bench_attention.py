@@ -35,7 +35,8 @@ def timeit(fn, reps=20):
 fl = 4.0 * B * H * N * N * 64
 byt_f = B * N * 4 * H * 64 * 2
 byt_b = B * N * 8 * H * 64 * 2
-rows = {"fwd": [], "fwd tiled (SFCVIT_ATTN_LONG=0)": [], "bwd fused": [], "bwd two-kernel": [], "bwd two-kernel, tiled (SFCVIT_ATTN_LONG=0)": []}
+rows = {"fwd": [], "fwd tiled (SFCVIT_ATTN_LONG=0)": [], "bwd fused": [],
+        "bwd fused, no start-up stagger": [], "bwd two-kernel": [], "bwd two-kernel, tiled (SFCVIT_ATTN_LONG=0)": []}
 for rnd in range(5):
     rows["fwd"].append(timeit(lambda: ops.attention_fwd(qkv, H, p, 5)))
     os.environ["SFCVIT_ATTN_LONG"] = "0"
@@ -43,6 +44,9 @@ for rnd in range(5):
     os.environ["SFCVIT_ATTN_LONG"] = "1"
     os.environ["SFCVIT_ATTN_BWD_FUSED"] = "1"
     rows["bwd fused"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
+    os.environ["SFCVIT_ATTN_STAGGER_BWD"] = "1,0"
+    rows["bwd fused, no start-up stagger"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
+    del os.environ["SFCVIT_ATTN_STAGGER_BWD"]
     os.environ["SFCVIT_ATTN_BWD_FUSED"] = "0"
     rows["bwd two-kernel"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
     os.environ["SFCVIT_ATTN_LONG"] = "0"
