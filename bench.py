@@ -15,13 +15,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement).
 
 What the line's roofline numbers are, so that they can be recomputed from profiles/ alone:
   * `roofline`      the dominant kernel FAMILY of the step: all instantiations of the persistent 8-phase GEMM
-                    `gemm8p_kernel<NI, MASK>` (every forward and dX GEMM).  achieved = sum of 2MNK over the family's
+                    `gemm8p_kernel<NI, MASK, P2>` (every forward and dX GEMM).  achieved = sum of 2MNK over the family's
                     launches in the timed region / sum of their HIP-event durations (events on the launching stream);
                     peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).  `traffic` = launch-weighted mean of the
                     family's HBM-side bytes per launch from the PMC passes in profiles/traffic.json for THIS workload
                     (null when the workload has no PMC pass); `algorithmic_bytes` beside it.
   * `roofline_detail`  the same quantity for: every GEMM symbol, the worst GEMM, the weight-gradient kernel
-                    (`gemm8p_km_kernel`), attention forward / backward (both bounds: FLOP/s of 2.5 PF and algorithmic
+                    (`gemm8p_km_kernel<P2>`), attention forward / backward (both bounds: FLOP/s of 2.5 PF and algorithmic
                     bytes/s of 8 TB/s -- at N = 196, hd = 64 attention is below the ridge, i.e. HBM-bound), the fused
                     gather + patch-embed kernels (both bounds) and the whole step.
   * `cpu_baseline`  the oracle's fp32 PyTorch-CPU restatement of the reference path timed on the host cores
@@ -238,7 +238,8 @@ def main():
     model = build(args.workload, args.dropout).to(dev, dtype=torch.bfloat16)
     model.train() if args.dropout > 0 else model.eval()    # eval() only switches dropout off; grads flow
     opt = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=5e-5, max_grad_norm=1.0)
-    reducer = GradReducer(opt) if world > 1 else None
+    # with --graph the collectives run between two graphs (forward + backward | optimizer), not from autograd hooks
+    reducer = GradReducer(opt, overlap=not args.graph) if world > 1 else None
 
     g = torch.Generator(device=dev).manual_seed(42 + rank)   # per-rank data, identical init
     images = torch.randn(batch, 3, img, img, device=dev, generator=g)
@@ -253,9 +254,7 @@ def main():
     step = lambda: train_step(model, images, targets, opt, reducer=reducer)     # noqa: E731
     if args.graph:
         from sfcvit.training import GraphedTrainStep
-        if world > 1:
-            raise SystemExit("--graph: single-GPU only (the collectives are launched from autograd hooks)")
-        step = GraphedTrainStep(model, images, targets, opt, warmup=max(2, args.warmup), preserve_state=False)   # its warm-up steps ARE the warm-up
+        step = GraphedTrainStep(model, images, targets, opt, warmup=max(2, args.warmup), preserve_state=False, reducer=reducer)   # its warm-up steps ARE the warm-up
 
     for _ in range(args.warmup):
         loss = step()

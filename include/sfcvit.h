@@ -217,7 +217,7 @@ int sfcvit_gemm(const sfcvit_gemm_args *a, void *stream);
 /* HOST: workspace bytes for a call with colsum_out. */
 int64_t sfcvit_gemm_colsum_workspace(int M, int N);
 /* HOST: name of the kernel the calling thread's last sfcvit_gemm launched, as rocprofv3 prints it (without the
- * namespace), e.g. "gemm8p_kernel<7, 6>" -- lets a benchmark key its live timings by kernel symbol. */
+ * namespace), e.g. "gemm8p_kernel<7, 6, true>" -- lets a benchmark key its live timings by kernel symbol. */
 int sfcvit_last_gemm_kernel(char *buf, int n);
 /* HOST: bytes of workspace sfcvit_gemm needs for this split (0 when splitk <= 1). */
 int64_t sfcvit_gemm_workspace(int M, int N, int splitk);

@@ -318,7 +318,7 @@ int check_args(const sfcvit_attn_args *a, const char *what, bool bwd) {
 int attn_seq_fwd(const sfcvit_attn_args &a, hipStream_t s);
 int attn_seq_bwd(const sfcvit_attn_args &a, hipStream_t s);
 // attention_bwd_fused.hip: dK, dV and dQ in one pass (head dim 64, N <= 224); -1 when not eligible.
-int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s);
+int attn_seq_bwd_fused(const sfcvit_attn_args &a, int dq_sums, hipStream_t s);
 // attention_wide.hip: head dims 128 / 192 / 256; return -1 for head dim 64.
 int attn_wide_fwd(const sfcvit_attn_args &a, hipStream_t s);
 int attn_wide_bwd(const sfcvit_attn_args &a, hipStream_t s);
@@ -360,9 +360,18 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
         if (!(env && env[0] == '0')) {
             sfcvit_attn_args f = *a;
             if (!a->colsum_out) f.colsum_part = nullptr;
-            if (int rc = attn_seq_bwd_fused(f, s); rc >= 0) {
+            // The column sums of dK and dV leave the kernel as 128 floats per workgroup (its key waves hold whole columns).
+            // Those of dQ are cheaper from a pass over the Q third of the dqkv just written (77 MB at ViT-B / 256: 16 us) than
+            // from the two dQ waves, whose per-chunk lane reductions + LDS read-modify-writes made them the slowest waves of a
+            // chunk (+37 us per launch, measured: 289.5 vs 252.8 us).  SFCVIT_ATTN_DQSUM=kernel restores the in-kernel sums (A/B).
+            const char *dq = getenv("SFCVIT_ATTN_DQSUM");
+            const int dq_in_kernel = dq && dq[0] == 'k';
+            if (int rc = attn_seq_bwd_fused(f, dq_in_kernel, s); rc >= 0) {
                 if (rc || !a->colsum_out) return rc;
-                return launch_colsum_reduce(a->colsum_part, a->B, D3, a->colsum_out, a->colsum_bf16, stream);
+                if (int rc2 = launch_colsum_reduce(a->colsum_part, a->B, D3, a->colsum_out, a->colsum_bf16, stream)) return rc2;
+                if (dq_in_kernel) return SFCVIT_OK;
+                const int Dq = a->H * a->hd;                      // the Q third: columns 0 .. D-1 of dqkv, overwrites the zeros
+                return sfcvit_colsum(a->dqkv, a->B * a->N, Dq, D3, a->colsum_out, a->colsum_bf16, a->colsum_part, a->colsum_part_bytes, stream);
             }
         }
     }

@@ -68,7 +68,7 @@ __device__ __forceinline__ bf16x8 ds_tr_frag(const char *slot, int key0, int lan
 // NFC: number of 16-row fragments at compile time (0 = from N); DROP: dropout on the probabilities (compile-time: a
 // runtime flag put a branch around every hash, each one a scheduling barrier between the MFMAs).
 template <int NFC, bool DROP>
-__global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_attn_args a, int npad, int stag_round, int stag_per, int stag_ticks) {
+__global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_attn_args a, int npad, int stag_round, int stag_per, int stag_ticks, int dq_sums) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stagger_start(stag_round, stag_per, stag_ticks);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
                 }
             }
             mfma_fence();
-            if (a.colsum_part) {
+            if (a.colsum_part && dq_sums) {
                 // column sums of this chunk's dQ tiles, accumulated in this wave's 32 LDS words (one writer per word, chunk
                 // after chunk: a fixed order; registers for running sums are not to be had).  Padded queries have dS = 0.
 #pragma unroll
@@ -328,16 +328,16 @@ constexpr int FUSED_MAX_N = 32 * FMAXC;
 constexpr int FUSED_MAX_LDS = FUSED_MAX_N * FUSED_ROW_BYTES + FUSED_EXTRA;
 
 template <int NFC, bool DROP>
-int launch_fused(const sfcvit_attn_args &a, int npad, size_t lds, int round, int per, int ticks, hipStream_t s) {
+int launch_fused(const sfcvit_attn_args &a, int npad, size_t lds, int round, int per, int ticks, int dq_sums, hipStream_t s) {
     if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<NFC, DROP>), FUSED_MAX_LDS, "attention_bwd_fused attribute")) return rc;
-    hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<NFC, DROP>), dim3(a.H, a.B), dim3(FT), lds, s, a, npad, round, per, ticks);
+    hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<NFC, DROP>), dim3(a.H, a.B), dim3(FT), lds, s, a, npad, round, per, ticks, dq_sums);
     return check_launch("attention_bwd_fused");
 }
 
 }  // namespace
 
 // -1: not eligible (the caller falls back to the two-kernel form); else a status.
-int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s) {
+int attn_seq_bwd_fused(const sfcvit_attn_args &a, int dq_sums, hipStream_t s) {
     if (a.hd != HD || a.N > FUSED_MAX_N) return -1;
     const int npad = (a.N + 31) / 32 * 32;
     const bool nf13 = (a.N + 15) / 16 == 13, drop = a.dropout_p > 0.f;
@@ -350,8 +350,8 @@ int attn_seq_bwd_fused(const sfcvit_attn_args &a, hipStream_t s) {
     if (slots < 1) slots = 1;
     const int round = 256, per = (round + slots - 1) / slots;
     note_attn_kernel("attn_seq_bwd_fused_kernel<%d, %s>", nf13 ? 13 : 0, drop ? "true" : "false");
-    if (nf13) return drop ? launch_fused<13, true>(a, npad, lds, round, per, ticks, s) : launch_fused<13, false>(a, npad, lds, round, per, ticks, s);
-    return drop ? launch_fused<0, true>(a, npad, lds, round, per, ticks, s) : launch_fused<0, false>(a, npad, lds, round, per, ticks, s);
+    if (nf13) return drop ? launch_fused<13, true>(a, npad, lds, round, per, ticks, dq_sums, s) : launch_fused<13, false>(a, npad, lds, round, per, ticks, dq_sums, s);
+    return drop ? launch_fused<0, true>(a, npad, lds, round, per, ticks, dq_sums, s) : launch_fused<0, false>(a, npad, lds, round, per, ticks, dq_sums, s);
 }
 
 }  // namespace sfcvit

@@ -127,16 +127,11 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_a
                     s[kf][r] = fast_exp2(s[kf][r] * c2 - mc);
                     l += s[kf][r];
                 }
-                if (drop) {                                          // 1 / (1 - p) is applied with 1 / l at the store
-                    bool k[4];
-                    drop_keep2(drk, uint32_t(8 * kf + 2 * (lane >> 4)), dth, k[0], k[1]);
-                    drop_keep2(drk, uint32_t(8 * kf + 2 * (lane >> 4)) + 1, dth, k[2], k[3]);
+                if (drop) {
+                    float keep[4];
+                    drop_keep4(drk, 16 * kf + 4 * (lane >> 4), dth, dsc, keep);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        s[kf][r] = k[r] ? s[kf][r] : 0.f;
-                        asm volatile("" ::"v"(s[kf][r]));     // pins the select here: without an anchor per element hipcc hoists
-                                                              // all 52 hashes of the row ahead of their uses and spills
-                    }
+                    for (int r = 0; r < 4; r++) s[kf][r] *= keep[r];
                 }
             }
         l = group_sum(l);
@@ -162,7 +157,7 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_a
                 }
         }
         mfma_fence();
-        store_rows(out, D, q, q < N, acc, (drop ? dsc : 1.f) / l, lane);
+        store_rows(out, D, q, q < N, acc, 1.f / l, lane);
         if (q < N && lane < 16) a.lse[(size_t(b) * a.H + h) * N + q] = mx * a.scale + __logf(l);
     }
 }

@@ -70,8 +70,8 @@ extern "C" int sfcvit_last_gemm_kernel(char *buf, int n) {
     if (!buf || n <= 0) return SFCVIT_EINVAL;
     const char *tf[2] = {"false", "true"};
     switch (g_gemm[0]) {
-    case 1: snprintf(buf, size_t(n), "gemm8p_kernel<%d, %d>", g_gemm[1], g_gemm[2]); break;
-    case 2: snprintf(buf, size_t(n), "gemm8p_km_kernel"); break;
+    case 1: snprintf(buf, size_t(n), "gemm8p_kernel<%d, %d, %s>", g_gemm[1], g_gemm[2], tf[g_gemm[3] & 1]); break;
+    case 2: snprintf(buf, size_t(n), "gemm8p_km_kernel<%s>", tf[g_gemm[1] & 1]); break;
     case 3: snprintf(buf, size_t(n), "gemm256_kernel<%s, %s, %d, %s>", tf[g_gemm[1] & 1], tf[g_gemm[2] & 1], g_gemm[3], tf[g_gemm[4] & 1]); break;
     case 4: snprintf(buf, size_t(n), "gemm_kernel<%s, %s, %s>", tf[g_gemm[1] & 1], tf[g_gemm[2] & 1], tf[g_gemm[3] & 1]); break;
     default: snprintf(buf, size_t(n), "none"); break;

@@ -17,7 +17,7 @@ int check_launch(const char *what);
 int raise_lds_limit(const void *kernel, int bytes, const char *what);
 
 // Which GEMM kernel the calling thread's last sfcvit_gemm launched (sfcvit_last_gemm_kernel formats it as the symbol
-// rocprofv3 shows): family 1 gemm8p_kernel<a, b>, 2 gemm8p_km_kernel, 3 gemm256_kernel<a, b, c, d>, 4 gemm_kernel<a, b, c>.
+// rocprofv3 shows): family 1 gemm8p_kernel<a, b, c>, 2 gemm8p_km_kernel<a>, 3 gemm256_kernel<a, b, c, d>, 4 gemm_kernel<a, b, c>.
 void note_gemm_kernel(int family, int a = 0, int b = 0, int c = 0, int d = 0);
 // Which attention kernel the calling thread's last sfcvit_attention_fwd / _bwd launched (its main kernel, named as
 // rocprofv3 names it); fmt is printf-style.

@@ -229,7 +229,10 @@ static int gemm_impl(const sfcvit_gemm_args *a, void *stream) {
             t.workspace_bytes = 0;
             t.force_generic = 1;
             if (int rc = gemm_impl(&t, stream)) return rc;
-            note_gemm_kernel(2);                                 // what ran is the 8-phase weight-gradient kernel (+ its tail)
+            {   // what ran is the 8-phase weight-gradient kernel (+ its tail)
+                const char *e = getenv("SFCVIT_GEMM_2PHASE");
+                note_gemm_kernel(2, !(e && e[0] == '0'));
+            }
             used++;
         }
         if (p8 == 0) {

@@ -93,9 +93,9 @@ struct StoreMap {
 };
 
 template <int MASK>
-__device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, int n, float (&v)[16], const float (&bv)[16],
-                                             const u32x4 (&side)[2], uint32_t thresh, float keep_scale, float dact_scale,
-                                             const StoreMap &sm, uint32_t rk_in0, uint32_t rk_in1) {
+__device__ __forceinline__ void epilogue_math(const sfcvit_gemm_args &g, int m, int n, float (&v)[16], const float (&bv)[16],
+                                              const u32x4 (&side)[2], uint32_t thresh, float keep_scale, float dact_scale,
+                                              uint32_t rk_in0, uint32_t rk_in1, u32x4 &w0, u32x4 &w1) {
     if (!(MASK & DACT)) {                                       // gradient GEMMs carry no bias (the dispatcher checks)
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] += bv[r];
@@ -144,27 +144,57 @@ __device__ __forceinline__ void epilogue_row(const sfcvit_gemm_args &g, int m, i
             for (int r = 0; r < 16; r++) v[r] = a[r] > 0.f ? v[r] * dact_scale : 0.f;
         }
     }
-    uint16_t *c = static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n;
-    // In the fragment layout a store instruction touches 64 different 64-byte segments (16 rows per quarter-wave,
-    // 16 bytes each): the vector-memory pipe takes them one by one, and the next tile's LDS-DMA queues behind them.
-    // Through the patch an instruction writes 8 rows x 128 contiguous bytes.  LDS operations of one wave execute in
-    // order, so write -> read needs no wait in between; inline asm because hipcc would put `s_waitcnt vmcnt(0)` in
-    // front of ordinary LDS accesses while LDS-DMA (and the previous row's stores) are in flight.
-    // (the reads return into the registers the writes took their data from: the LDS pipe has consumed them by then)
-    u32x4 w0 = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-    u32x4 w1 = {pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
-    asm volatile("ds_write_b128 %2, %0\n\tds_write_b128 %3, %1\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "+v"(w0), "+v"(w1)
-                 : "v"(sm.wa), "v"(sm.wa ^ 16), "v"(sm.ra)
-                 : "memory");
-    c += sm.coff;
-    // Streaming stores (system scope + non-temporal): C is far larger than the L2 and is next read by another kernel;
-    // written through, it does not push the B panel and the A rows the other workgroups are loading out of the L2
-    // (measured with the cache-policy bits one by one, same process: plain 181 / 246 / 227 us for QKV / FFN1 / FFN2
-    // forward, `nt` 170 / 226 / 219, `sc0 sc1 nt` 170 / 219 / 215).  From asm because the builtin only has `nt`;
-    // s_nop: the store-data hazard (a VALU write of these registers right behind a wide store) is hipcc's to pad
-    // only for stores it emitted itself.
+    w0 = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    w1 = u32x4{pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15])};
+}
+
+// Fragment layout -> row-contiguous layout for NR packed rows of a wave, through the wave-private LDS patch.  In the
+// fragment layout a store instruction touches 64 different 64-byte segments (16 rows per quarter-wave, 16 bytes each): the
+// vector-memory pipe takes them one by one, and the next tile's LDS-DMA queues behind them; through the patch an instruction
+// writes 8 rows x 128 contiguous bytes.  ONE asm statement for all rows, one wait at its end: LDS operations of a wave
+// execute in order, so row i + 1's writes may follow row i's reads without a wait in between (the patch is reused row after
+// row; the reads return into the registers the writes took their data from, which the LDS pipe has consumed by then), and
+// the ~200-clock round trip is paid once per batch -- round 2 waited after every row, 7-8 exposed round trips per epilogue.
+// Inline asm because hipcc would put `s_waitcnt vmcnt(0)` in front of ordinary LDS accesses while LDS-DMA is in flight.
+#define SFCVIT_XROW(a, b) "ds_write_b128 %[wa], " a "\n\tds_write_b128 %[wb], " b "\n\tds_read_b128 " a ", %[ra]\n\tds_read_b128 " b ", %[ra] offset:1024\n\t"
+template <int NR>
+__device__ __forceinline__ void patch_exchange(u32x4 (&w)[NR][2], const StoreMap &sm) {
+    static_assert(NR >= 1 && NR <= 8, "rows per batch");
+    const int wa = sm.wa, wb = sm.wa ^ 16, ra = sm.ra;
+    if constexpr (NR == 8)
+        asm volatile(SFCVIT_XROW("%0", "%1") SFCVIT_XROW("%2", "%3") SFCVIT_XROW("%4", "%5") SFCVIT_XROW("%6", "%7")
+                     SFCVIT_XROW("%8", "%9") SFCVIT_XROW("%10", "%11") SFCVIT_XROW("%12", "%13") SFCVIT_XROW("%14", "%15") "s_waitcnt lgkmcnt(0)"
+                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1]),
+                       "+v"(w[4][0]), "+v"(w[4][1]), "+v"(w[5][0]), "+v"(w[5][1]), "+v"(w[6][0]), "+v"(w[6][1]), "+v"(w[7][0]), "+v"(w[7][1])
+                     : [wa] "v"(wa), [wb] "v"(wb), [ra] "v"(ra) : "memory");
+    else if constexpr (NR == 7)
+        asm volatile(SFCVIT_XROW("%0", "%1") SFCVIT_XROW("%2", "%3") SFCVIT_XROW("%4", "%5") SFCVIT_XROW("%6", "%7")
+                     SFCVIT_XROW("%8", "%9") SFCVIT_XROW("%10", "%11") SFCVIT_XROW("%12", "%13") "s_waitcnt lgkmcnt(0)"
+                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1]),
+                       "+v"(w[4][0]), "+v"(w[4][1]), "+v"(w[5][0]), "+v"(w[5][1]), "+v"(w[6][0]), "+v"(w[6][1])
+                     : [wa] "v"(wa), [wb] "v"(wb), [ra] "v"(ra) : "memory");
+    else if constexpr (NR == 6)
+        asm volatile(SFCVIT_XROW("%0", "%1") SFCVIT_XROW("%2", "%3") SFCVIT_XROW("%4", "%5") SFCVIT_XROW("%6", "%7")
+                     SFCVIT_XROW("%8", "%9") SFCVIT_XROW("%10", "%11") "s_waitcnt lgkmcnt(0)"
+                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1]),
+                       "+v"(w[4][0]), "+v"(w[4][1]), "+v"(w[5][0]), "+v"(w[5][1])
+                     : [wa] "v"(wa), [wb] "v"(wb), [ra] "v"(ra) : "memory");
+    else if constexpr (NR == 4)
+        asm volatile(SFCVIT_XROW("%0", "%1") SFCVIT_XROW("%2", "%3") SFCVIT_XROW("%4", "%5") SFCVIT_XROW("%6", "%7") "s_waitcnt lgkmcnt(0)"
+                     : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1])
+                     : [wa] "v"(wa), [wb] "v"(wb), [ra] "v"(ra) : "memory");
+    else
+        static_assert(NR == 8, "patch_exchange: batch sizes 4, 6, 7, 8");
+}
+#undef SFCVIT_XROW
+
+// Streaming stores (system scope + non-temporal) of one exchanged row pair: C is far larger than the L2 and is next read
+// by another kernel; written through, it does not push the B panel and the A rows the other workgroups are loading out of
+// the L2 (measured with the cache-policy bits one by one, same process: plain 181 / 246 / 227 us for QKV / FFN1 / FFN2
+// forward, `nt` 170 / 226 / 219, `sc0 sc1 nt` 170 / 219 / 215).  From asm because the builtin only has `nt`; s_nop: the
+// store-data hazard (a VALU write of these registers right behind a wide store) is hipcc's to pad only for its own stores.
+__device__ __forceinline__ void store_row_pair(const sfcvit_gemm_args &g, int m, int n, const StoreMap &sm, const u32x4 &w0, const u32x4 &w1) {
+    uint16_t *c = static_cast<uint16_t *>(g.c) + size_t(m) * g.ldc + n + sm.coff;
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(c), "v"(w0) : "memory");
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(c + size_t(8) * g.ldc), "v"(w1) : "memory");
 }
@@ -417,21 +447,26 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
                     side[i - i0][1] = *reinterpret_cast<const u32x4 *>(p + 8);
                 }
             }
+            u32x4 pk[i1 - i0][2];                                   // the packed rows of this batch (half the accumulators' registers)
             static_for<i0, i1>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 float v[16] = {acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3], acc[i][1][0], acc[i][1][1],
                                acc[i][1][2], acc[i][1][3], acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3],
                                acc[i][3][0], acc[i][3][1], acc[i][3][2], acc[i][3][3]};
-                epilogue_row<MASK>(g, m0 + 16 * i, n0, v, bv, side[i - i0], thresh, keep_scale, dact_scale, sm, rk_in0, rk_in1);
+                epilogue_math<MASK>(g, m0 + 16 * i, n0, v, bv, side[i - i0], thresh, keep_scale, dact_scale, rk_in0, rk_in1,
+                                    pk[i - i0][0], pk[i - i0][1]);
                 if (MASK & CSUM) {
                     const bool own = m0 + 16 * i >= m_new;           // a row the overlapping last tile shares is summed once
 #pragma unroll
-                    for (int r = 0; r < 16; r++) cs[r] += own ? v[r] : 0.f;      // the fp32 values that were just stored as bf16
+                    for (int r = 0; r < 16; r++) cs[r] += own ? v[r] : 0.f;      // the fp32 values that are stored as bf16
                 }
             });
+            patch_exchange<i1 - i0>(pk, sm);
+            static_for<i0, i1>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                store_row_pair(g, m0 + 16 * i, n0, sm, pk[i - i0][0], pk[i - i0][1]);
+            });
         };
-        // no registers for the side operand of 8 rows beside the hash (DROP | RES) or beside the column sums (DACT | CSUM
-        // reading the stored activation rather than its bit mask)
         if constexpr (NI == 8 && ((MASK & (DROP | RES)) == (DROP | RES) || (MASK & (DACT | CSUM | BITS)) == (DACT | CSUM))) {
             batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
             batch(std::integral_constant<int, 4>{}, std::integral_constant<int, NI>{});
@@ -890,9 +925,9 @@ int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
     const int LDS_TOTAL = LDS_BIAS + (a.bias ? a.N * 2 : 0);
     unsigned *counters = queue_counters(s);
     if (!counters) return fail(SFCVIT_ELAUNCH, "gemm8p: could not allocate the tile-queue counters");
-    note_gemm_kernel(1, NI, MASK);
     // the two-phase k-tile schedule is the default; SFCVIT_GEMM_2PHASE=0 selects the four-phase one (A/B in one process)
     const char *e = getenv("SFCVIT_GEMM_2PHASE");
+    note_gemm_kernel(1, NI, MASK, !(e && e[0] == '0'));
     if (!(e && e[0] == '0')) {
         if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK, true>), LDS_MAX, "gemm8p attribute")) return rc;
         hipLaunchKernelGGL((gemm8p_kernel<NI, MASK, true>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters);
@@ -948,10 +983,10 @@ int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_us
     int kps = ((KT + splits - 1) / splits + 1) / 2 * 2;           // k-tiles per split, even
     splits = (KT + kps - 1) / kps;
     if (splits < 2) return -1;
-    note_gemm_kernel(2);
     sfcvit_gemm_args body = a;
     body.K = Kb;
     const char *e = getenv("SFCVIT_GEMM_2PHASE");              // "0": the four-phase k-tile schedule (A/B in one process)
+    note_gemm_kernel(2, !(e && e[0] == '0'));
     if (e && e[0] == '0') {
         if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_km_kernel<false>), LDS_BYTES, "gemm8p_km attribute")) return rc;
         hipLaunchKernelGGL(gemm8p_km_kernel<false>, dim3((tiles * splits + 7) / 8 * 8), dim3(T), LDS_BYTES, s, body, kps, splits);

@@ -116,7 +116,7 @@ def main():
                                 num_classes=a.classes).to(device, dtype=torch.bfloat16)   # main.py:157: bf16 parameters
     train_criterion, test_criterion = SoftTargetCrossEntropy(), nn.CrossEntropyLoss()
     optimizer = FusedAdamW(model.parameters(), lr=a.lr, weight_decay=a.weight_decay, max_grad_norm=1.0)
-    reducer = GradReducer(optimizer) if world > 1 else None
+    reducer = GradReducer(optimizer, overlap=not a.graph) if world > 1 else None    # --graph: collectives between two graphs
     scheduler = WarmupCosine(optimizer, a.warmup_epochs * len(train_loader), a.epochs * len(train_loader))
     start_epoch, best = 0, 0.0
     if a.resume:
@@ -125,25 +125,22 @@ def main():
         msd = {(k[len("_orig_mod."):] if k.startswith("_orig_mod.") else k): v for k, v in ck["model_state_dict"].items()}
         model.load_state_dict(msd)
         osd = ck.get("optimizer_state_dict") or {}
-        ours = "active" in osd and "master" in osd           # this repository's flat fp32 state (FusedAdamW.state_dict)
-        if osd and not ours and not a.resume_model_only:
-            print("--resume: the optimizer state is not FusedAdamW's (a reference checkpoint?): weights restored, "
-                  "optimizer and schedule start fresh (INTEGRATION.md, Checkpoints)")
-        if ours and not a.resume_model_only:
-            optimizer.load_state_dict(osd)                                     # fp32 master weights + Adam moments
+        if osd and not a.resume_model_only:
+            # this repository's flat fp32 state (FusedAdamW.state_dict), or a torch.optim.AdamW state_dict as the reference's
+            # checkpoints hold (main.py:345-354): Adam moments and step count are mapped into the flat buffers
+            optimizer.load_state_dict(osd)
             start_epoch, best = ck["epoch"] + 1, ck.get("test_acc", 0.0)
-            scheduler.n = ck.get("scheduler_state_dict", {}).get("n", start_epoch * len(train_loader))
+            ssd = ck.get("scheduler_state_dict") or {}
+            # ours: {"n": steps taken}; the reference's LambdaLR (transformers' cosine schedule): {"last_epoch": steps taken}
+            scheduler.n = ssd.get("n", ssd.get("last_epoch", start_epoch * len(train_loader)))
             optimizer.lr = scheduler.lr_at(scheduler.n)
     os.makedirs(a.checkpoint_dir, exist_ok=True)
     ckpt = os.path.join(a.checkpoint_dir, f"checkpoint_{a.tokenizer}.pt")
     graphed = None
     if a.graph:
-        if world > 1:
-            raise SystemExit("--graph captures one process's step; the data-parallel reducer launches its collectives from "
-                             "autograd hooks and is not captured")
         model.train()
         graphed = GraphedTrainStep(model, torch.zeros(per_rank, 3, a.img_size, a.img_size, device=device),
-                                   torch.zeros(per_rank, a.classes, device=device), optimizer, scheduler)
+                                   torch.zeros(per_rank, a.classes, device=device), optimizer, scheduler, reducer=reducer)
 
     for epoch in range(start_epoch, a.epochs):
         tr_loss, tr_acc = train_with_mixup_or_cutmix(model, train_loader, train_criterion, optimizer, scheduler,

@@ -273,6 +273,31 @@ def gelu(x):
     return _Gelu.apply(_bf(x))
 
 
+class _GeluDrop(Function):
+    """dropout_p(gelu_erf(x)) in one pass, the mask regenerated in backward (nn.GELU followed by nn.Dropout:
+    MultiLayerPredictor's hidden layers, src/models/vit.py:303-318)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        ctx.p, ctx.seed, ctx.shape = p, seed, x.shape
+        return ops.gelu_drop_fwd(x.view(-1, x.shape[-1]), p, seed).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = ops.gelu_drop_bwd(_c(dy).view(-1, x.shape[-1]), x.view(-1, x.shape[-1]), ctx.p, ctx.seed)
+        return dx.view(ctx.shape), None, None
+
+
+def gelu_dropout(x, p):
+    """Dropout(p)(GELU(x)), training mode (p > 0 draws a fresh mask per call; p = 0 is gelu)."""
+    if p <= 0:
+        return gelu(x)
+    return _GeluDrop.apply(_bf(x), float(p), ops.next_seed())
+
+
 class _Attention(Function):
     """softmax(q k^T / sqrt(hd)) v per head on a packed projection [B, N, 3 * H * hd] (q | k | v thirds, head h at
     columns h*hd.. of each third): the core of nn.MultiheadAttention and of altvit.Attention (altvit.py:131-142)."""
@@ -569,6 +594,6 @@ def soft_target_cross_entropy(logits, targets):
 # (used by the hierarchical tokenizers, altvit and MultiLayerPredictor(n_layers > 2)) stay opaque: Dynamo breaks the graph
 # around each and runs it as written.
 # ----------------------------------------------------------------------------
-for _name in ("hier_tokenizer", "linear", "layer_norm", "gelu", "attention"):
+for _name in ("hier_tokenizer", "linear", "layer_norm", "gelu", "gelu_dropout", "attention"):
     globals()[_name] = torch.compiler.disable(globals()[_name], recursive=True)
 del _name

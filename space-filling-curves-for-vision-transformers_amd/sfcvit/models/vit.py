@@ -106,20 +106,26 @@ class MultiLayerPredictor(nn.Sequential):
             ln, fact, fc = self[0], self[1], self[4]
             return F.predictor_head(x, ln.weight, ln.bias, fact.W_emb, fact.W_seq, fc.weight, fc.bias, ln.eps,
                                     dropout_p=p)
-        if p > 0:
-            raise NotImplementedError("training-mode dropout of MultiLayerPredictor is fused only for n_layers == 2 "
-                                      "(the form VisionTransformer{,1D} build)")
-        for m in self:
+        # any depth (vit.py:310-318): every nn.GELU here is followed by its nn.Dropout -- one fused pass per pair
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
             if isinstance(m, nn.LayerNorm):
                 x = F.layer_norm(x, m.weight, m.bias, m.eps)
             elif isinstance(m, nn.Linear):
                 x = F.linear(x, m.weight, m.bias)
+            elif isinstance(m, nn.GELU) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.Dropout):
+                x = F.gelu_dropout(x, p)
+                i += 1
             elif isinstance(m, nn.GELU):
                 x = F.gelu(x)
             elif isinstance(m, nn.Dropout):
-                pass                      # p = 0 here (checked above)
+                if p > 0:
+                    raise NotImplementedError("a Dropout that does not follow a GELU")
             else:
                 x = m(x)
+            i += 1
         return x
 
 

@@ -56,9 +56,15 @@ def _dbg(msg):
 
 
 class GradReducer:
-    def __init__(self, optimizer, bucket_bytes=32 << 20, group=None):
+    """overlap=True (default): buckets are all-reduced from post-accumulate-grad hooks while backward is still running.
+    overlap=False: no hooks -- finish() launches every bucket itself.  That is the mode a GraphedTrainStep needs (forward
+    + backward replay from one hipGraph, in which hooks cannot run; the collectives are issued between that graph and
+    the optimizer's), and it costs the overlap with backward, not correctness: same buckets, same sums."""
+
+    def __init__(self, optimizer, bucket_bytes=32 << 20, group=None, overlap=True):
         self.opt = optimizer
         self.group = group
+        self.overlap = overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_bytes = bucket_bytes
         self.buckets = None          # [(start, end)] element ranges of flat_grad
@@ -111,8 +117,9 @@ class GradReducer:
             self._members.append(last - first)
             for _, _, p in views[first:last]:
                 self._param_bucket[id(p)] = len(self.buckets) - 1
-        for _, _, p in views:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self.overlap:
+            for _, _, p in views:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._host_staged = self.world > 1 and self.backend == "gloo" and self.opt.flat_grad.is_cuda
         if self.world > 1:
             # replicas must start identical: rank 0's parameters win (same-seed construction already gives that; a
@@ -210,6 +217,10 @@ class GradReducer:
             if self.world > 1:
                 for b in range(len(self.buckets)):
                     self._launch(b)
+        elif not self.overlap:
+            self.opt.adopt_all()                 # gradients produced outside the slots move into the flat buffer first
+            for b in range(len(self.buckets)):
+                self._launch(b)
         elif self._pending is not None and any(self._pending):
             # a parameter did not fire (e.g. frozen this step): reduce its bucket anyway
             for b, left in enumerate(self._pending):

@@ -199,7 +199,42 @@ class FusedAdamW(FlatGradBuffer):
         return {"step": self.step_count, "lr": self.lr, "master": self.master, "m": self.m, "v": self.v,
                 "active": [index[id(p)] for p in self.active]}
 
+    def load_torch_state_dict(self, sd):
+        """The state_dict of a torch.optim.AdamW over the same model.parameters() (what the reference's main.py:345-354
+        checkpoints hold): per-parameter `step`, `exp_avg`, `exp_avg_sq` are mapped into the flat m / v buffers and the
+        step count, lr from its param group.  Parameters without a state entry there (never stepped: the token-mix branch
+        the forward does not use, vit.py:269-272) stay outside the flat buffers, as here.  The fp32 master weights are
+        taken from the model's (already loaded) parameters: torch.optim.AdamW keeps none."""
+        state, groups = sd["state"], sd["param_groups"]
+        order = [i for g in groups for i in g["params"]]
+        if len(order) != len(self.params):
+            raise ValueError(f"optimizer state is for {len(order)} parameters, this model has {len(self.params)}")
+        pos = {i: n for n, i in enumerate(order)}            # torch's parameter id -> position in model.parameters()
+        active = sorted(pos[i] for i in state)
+        if self.flat_grad is None:
+            self._build([self.params[n] for n in active])
+        elif [id(p) for p in self.active] != [id(self.params[n]) for n in active]:
+            raise ValueError("optimizer state covers a different set of parameters than the one already built")
+        steps = set()
+        for i, st in state.items():
+            p = self.params[pos[i]]
+            o = p._sfcvit_slot[1]
+            if st["exp_avg"].numel() != p.numel():
+                raise ValueError(f"optimizer state of parameter {pos[i]} has {st['exp_avg'].numel()} elements, expected {p.numel()}")
+            self.m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1).float())
+            self.v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1).float())
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"parameters were stepped a different number of times ({sorted(steps)}): one flat step count cannot hold that")
+        self.step_count = steps.pop() if steps else 0
+        if self.dev_state is not None:
+            self.dev_state[1] = self.step_count
+        self.lr = float(groups[0]["lr"])
+        self.master.copy_(self.flat_param.float())
+
     def load_state_dict(self, sd):
+        if "param_groups" in sd and "state" in sd:           # a torch.optim optimizer's state (reference checkpoint)
+            return self.load_torch_state_dict(sd)
         if self.flat_grad is None:
             self._build([self.params[i] for i in sd["active"]])
         if self.master.numel() != sd["master"].numel():

@@ -31,15 +31,21 @@ class GraphedTrainStep:
     `images` / `targets` are STATIC buffers: copy each new batch into them (`.copy_`) before calling; `.logits` is the
     static output of the last replay (accuracy bookkeeping of the epoch loops).  Needs the
     optimizer's device-resident step state (dropout seeds and Adam's step count would otherwise be frozen into the
-    graph as by-value kernel arguments); single process, no gradient reducer (its collectives are launched from
-    autograd hooks on another stream).  Shapes, model mode (train / eval) and dropout rates are fixed at capture.
+    graph as by-value kernel arguments).  Shapes, model mode (train / eval) and dropout rates are fixed at capture.
+    Data parallelism: pass `reducer=GradReducer(optimizer, overlap=False)`; the step is then TWO graphs -- forward +
+    backward, and clip + AdamW -- with the gradient all-reduce issued between them (collectives launched from autograd
+    hooks cannot replay from a graph; the price is their overlap with backward, which a launch-bound model -- the case
+    a graph is for -- does not miss).
     The warm-up steps before the capture are real optimisation steps on whatever the static buffers hold; with
     `preserve_state` (default) parameters, optimizer moments, step count and scheduler position are put back
     afterwards, so that a training script that switches to the graphed step trains exactly as before."""
 
-    def __init__(self, model, images, targets, optimizer, scheduler=None, warmup=3, preserve_state=True):
+    def __init__(self, model, images, targets, optimizer, scheduler=None, warmup=3, preserve_state=True, reducer=None):
         self.model, self.images, self.targets, self.opt, self.sched = model, images, targets, optimizer, scheduler
         self.logits = None
+        self.reducer = reducer
+        if reducer is not None and reducer.overlap:
+            raise ValueError("GraphedTrainStep needs GradReducer(optimizer, overlap=False): hooks cannot run inside a graph replay")
         optimizer.use_device_state(images.device)
         snap = self._snapshot() if preserve_state else None
         cur = torch.cuda.current_stream()
@@ -54,18 +60,35 @@ class GraphedTrainStep:
             self._restore(snap)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):            # records, does not run: device state and host mirror stay as they are
-            self.loss = self._step()
+        self.graph_opt = None
+        if reducer is None:
+            with torch.cuda.graph(self.graph):        # records, does not run: device state and host mirror stay as they are
+                self.loss = self._step()
+        else:                                         # two graphs around the collectives; one memory pool
+            with torch.cuda.graph(self.graph):
+                self.loss = self._fwd_bwd()
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                self.opt.step()
 
-    def _step(self):                                  # train_step() below, keeping the logits
+    def _fwd_bwd(self):
         self.opt.begin_step()
         self.opt.zero_grad()
         logits = self.model(self.images)
         loss = F.soft_target_cross_entropy(logits, self.targets)
         loss.backward()
-        self.opt.step()
+        if self.reducer is not None and self.opt.flat_grad is not None:
+            self.opt.adopt_all()                      # every gradient in the flat buffer before the collectives read it
         self.logits = logits.detach()
         return loss.detach()
+
+    def _step(self):                                  # train_step() below, keeping the logits
+        loss = self._fwd_bwd()
+        if self.reducer is not None:
+            self.reducer.begin_step()
+            self.reducer.finish()
+        self.opt.step()
+        return loss
 
     def _snapshot(self):
         o = self.opt
@@ -102,13 +125,17 @@ class GraphedTrainStep:
         if self.graph is None:
             raise RuntimeError("GraphedTrainStep was closed")
         self.graph.replay()
+        if self.graph_opt is not None:
+            self.reducer.begin_step()
+            self.reducer.finish()                     # SUM over the ranks; 1 / world is folded into the optimizer kernel
+            self.graph_opt.replay()
         self._after()
         return self.loss
 
     def close(self):
         """Drop the graph and hand the step state back to the host (FusedAdamW.release_device_state): the optimizer, the
         model and anything else in the process then behave as before the graphed step existed."""
-        self.graph = None
+        self.graph = self.graph_opt = None
         self.opt.release_device_state()
 
     def __enter__(self):
