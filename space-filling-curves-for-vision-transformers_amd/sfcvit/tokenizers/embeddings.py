@@ -78,9 +78,11 @@ class _FusedTokenizer(BasePatchEmbedding):
         torch.compile (the reference's order, main.py:252-284) never has to build them inside a traced forward."""
         out = super()._apply(fn, *args, **kwargs)
         dev = self.proj.weight.device
-        if dev.type == "cuda" and getattr(self, "_geom", None) is not None:
+        if dev.type == "cuda" and getattr(self, "_geom", None) is not None and self._static_order:
             self._pix_table(dev)
         return out
+
+    _static_order = True            # False: the token order changes from call to call (RandomEmbedding): nothing to prebuild
 
     def forward(self, x):
         img = self._geom[0]
@@ -255,6 +257,7 @@ class HilbertEmbedding(_Conv2dTokenizer):
 class RandomEmbedding(_Conv2dTokenizer):
     """src/tokenizers/_2D/random_embedding.py:6-37: a fresh torch.randperm(N) of the patches on every call
     (drawn from torch's CPU generator, as in the reference)."""
+    _static_order = False
 
     def forward(self, x):
         self._perm = torch.randperm(self.n_patches)
