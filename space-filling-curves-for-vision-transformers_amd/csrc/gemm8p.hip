@@ -202,9 +202,13 @@ __device__ __forceinline__ void store_row_pair(const sfcvit_gemm_args &g, int m,
 
 // P2 = the two-phase schedule of a k-tile (see ktile2 below): 4 barriers per k-tile instead of 8.
 template <int NI, int MASK, bool P2 = false>
-__global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, unsigned *__restrict__ counters) {
+__global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, unsigned *__restrict__ counters, int stag_slots, int stag_ticks) {
     constexpr int BM = 32 * NI, GR = 16 * NI;               // tile rows, rows per wave group
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: ring of 2 x [A0 | A1 | B0 | B1]
+    if (stag_ticks > 0) {   // start-up stagger (see launch()): the workgroups of an XCD start in `slots` groups, `ticks` x 10 ns apart
+        const uint64_t until = __builtin_amdgcn_s_memrealtime() + uint64_t((blockIdx.x >> 3) % stag_slots) * uint64_t(stag_ticks);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     // wid through readfirstlane: the compiler then knows that wr / wc (and the branches on them) are wave-uniform, and
     // keeps what those branches update -- the staging cursors -- in scalar registers
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 2, wc = wid & 3;
@@ -928,15 +932,26 @@ int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
     // the two-phase k-tile schedule is the default; SFCVIT_GEMM_2PHASE=0 selects the four-phase one (A/B in one process)
     const char *e = getenv("SFCVIT_GEMM_2PHASE");
     note_gemm_kernel(1, NI, MASK, !(e && e[0] == '0'));
+    // Start-up stagger: the 32 workgroups of an XCD start in 4 groups 2 us apart.  Uniform tiles keep the 256 workgroups of a
+    // launch in lockstep, so all of them reach their epilogue in the same microsecond and 33 MB of C hit the memory system at
+    // once (the epilogue section of the first tiles of a launch takes 10 000 clocks, 5 600 once the workgroups have drifted
+    // apart: profiles/r3/gemm8p_ktile_trace.txt); the tile queue absorbs the late starts (late workgroups draw fewer tiles).
+    // Measured alone, M = 50 176 (tools/gemm_lab/ab_two_phase.py with AB_STAGGER): QKV 148.9 -> 141.7 us, out-proj 74.4 ->
+    // 68.6, linear1 233.7 -> 230.9, linear2 208.0 -> 205.3, linear2 dX 225.8 -> 221.4, linear1 dX 206.6 -> 203.1, in_proj dX
+    // 162.0 -> 161.6; training step 33.26-33.38 -> 32.86-32.89 ms (three alternating pairs of runs on one box).
+    // SFCVIT_GEMM_STAGGER="slots,ticks" (10 ns) overrides; "1,0" = off.
+    int stag_slots = 4, stag_ticks = 200;
+    if (const char *st = getenv("SFCVIT_GEMM_STAGGER")) sscanf(st, "%d,%d", &stag_slots, &stag_ticks);
+    if (stag_slots < 1) stag_slots = 1;
     if (!(e && e[0] == '0')) {
         if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK, true>), LDS_MAX, "gemm8p attribute")) return rc;
-        hipLaunchKernelGGL((gemm8p_kernel<NI, MASK, true>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters);
+        hipLaunchKernelGGL((gemm8p_kernel<NI, MASK, true>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters, stag_slots, stag_ticks);
         const int rc = check_launch("gemm8p");
         if (rc) (void)hipMemsetAsync(counters, 0, SLOT_UINTS * sizeof(unsigned), s);
         return rc;
     }
     if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>), LDS_MAX, "gemm8p attribute")) return rc;
-    hipLaunchKernelGGL((gemm8p_kernel<NI, MASK>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters);
+    hipLaunchKernelGGL((gemm8p_kernel<NI, MASK>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters, stag_slots, stag_ticks);
     const int rc = check_launch("gemm8p");
     if (rc) (void)hipMemsetAsync(counters, 0, SLOT_UINTS * sizeof(unsigned), s);   // a launch that did not run leaves no debt
     return rc;

@@ -49,6 +49,19 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+STAG = os.environ.get("AB_STAGGER")           # e.g. "4,50;8,30": compare start-up staggers instead of the schedules
+if STAG:
+    for name, (fn, fl) in CASES.items():
+        if " km " in name:
+            continue
+        modes = ["1,0"] + STAG.split(";")
+        t = {m: [] for m in modes}
+        for rnd in range(7):
+            for m in modes:
+                os.environ["SFCVIT_GEMM_STAGGER"] = m
+                t[m].append(timeit(fn))
+        print(name, "  ".join(f"[{m}] {sorted(t[m])[3]:7.1f} us" for m in modes), flush=True)
+    sys.exit(0)
 for name, (fn, fl) in CASES.items():
     os.environ["SFCVIT_GEMM_2PHASE"] = "0"
     ref = fn().clone()
