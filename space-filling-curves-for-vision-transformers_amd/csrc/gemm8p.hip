@@ -943,6 +943,10 @@ int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
     int stag_slots = 4, stag_ticks = 200;
     if (const char *st = getenv("SFCVIT_GEMM_STAGGER")) sscanf(st, "%d,%d", &stag_slots, &stag_ticks);
     if (stag_slots < 1) stag_slots = 1;
+    {   // a launch whose workgroups draw one tile each has no lockstep to break: the delay would only lengthen it
+        const long ntiles = long((a.M + 32 * NI - 1) / (32 * NI)) * (a.N / 256);
+        if (ntiles < 2L * grid) stag_ticks = 0;
+    }
     if (!(e && e[0] == '0')) {
         if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK, true>), LDS_MAX, "gemm8p attribute")) return rc;
         hipLaunchKernelGGL((gemm8p_kernel<NI, MASK, true>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters, stag_slots, stag_ticks);

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const uint16_t *__restr
 // columns of dgamma / dbeta in registers, and the block writes one partial row
 // [2][D] to the workspace; ln_bwd_reduce sums the partials.
 // ---------------------------------------------------------------------------
-template <int VPL>
+template <int VPL, bool ADD, int AHEAD>
 __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
                                                          const float *__restrict__ mean, const float *__restrict__ rstd,
                                                          const uint16_t *__restrict__ gamma,
@@ -107,12 +107,12 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
 #pragma unroll
         for (int j = 0; j < 8; j++) dg[i][j] = db[i][j] = dc[i][j] = 0.f;
     }
-    // Rows are software-pipelined: the loads of this wave's next row are issued before the current row is reduced
+    // Rows are software-pipelined: the loads of this wave's next AHEAD rows are issued before the current row is reduced
     // (a row is load -> two wave reductions -> store, and only 8 waves per CU are resident: without the prefetch
-    // the kernel sat at 2.7-3.3 TB/s, latency- not bandwidth-bound).
+    // the kernel sat at 2.7-3.3 TB/s, latency- not bandwidth-bound; one row ahead keeps 24 KB per CU in flight, two 36 KB).
     const int stride = gridDim.x * WAVES;
-    u32x4 xr[VPL], dr[VPL], ar[VPL], xn[VPL], dn[VPL], an[VPL];
-    float mu = 0.f, rs = 0.f, mun = 0.f, rsn = 0.f;
+    u32x4 xr[VPL], dr[VPL], ar[VPL], xn[VPL], dn[VPL], an[VPL], xm[VPL], dm[VPL], am[VPL];
+    float mu = 0.f, rs = 0.f, mun = 0.f, rsn = 0.f, mum = 0.f, rsm = 0.f;
     auto load_row = [&](int row, u32x4 (&xq)[VPL], u32x4 (&dq)[VPL], u32x4 (&aq)[VPL], float &m, float &r) __attribute__((always_inline)) {
         m = mean[row];
         r = rstd[row];
@@ -122,15 +122,20 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
             if (c < nvec) {
                 xq[i] = *reinterpret_cast<const u32x4 *>(x + size_t(row) * D + c * 8);
                 dq[i] = *reinterpret_cast<const u32x4 *>(dy + size_t(row) * D + c * 8);
-                if (dx_add) aq[i] = *reinterpret_cast<const u32x4 *>(dx_add + size_t(row) * D + c * 8);
+                if (ADD) aq[i] = *reinterpret_cast<const u32x4 *>(dx_add + size_t(row) * D + c * 8);
             }
         }
     };
     int row = blockIdx.x * WAVES + wave;
     if (row < M) load_row(row, xr, dr, ar, mu, rs);
+    if (AHEAD == 2 && row + stride < M) load_row(row + stride, xn, dn, an, mun, rsn);
     for (; row < M; row += stride) {
         const bool more = row + stride < M;
-        if (more) load_row(row + stride, xn, dn, an, mun, rsn);
+        if (AHEAD == 2) {
+            if (row + 2 * stride < M) load_row(row + 2 * stride, xm, dm, am, mum, rsm);
+        } else if (more) {
+            load_row(row + stride, xn, dn, an, mun, rsn);
+        }
         float xh[VPL][8], gy[VPL][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) o[j] = rs * (gy[i][j] - c1 - xh[i][j] * c2);
-                if (dx_add) {
+                if (ADD) {
                     float a[8];
                     unpack8(ar[i], a);
 #pragma unroll
@@ -190,6 +195,12 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
             for (int i = 0; i < VPL; i++) { xr[i] = xn[i]; dr[i] = dn[i]; ar[i] = an[i]; }
             mu = mun;
             rs = rsn;
+            if (AHEAD == 2) {
+#pragma unroll
+                for (int i = 0; i < VPL; i++) { xn[i] = xm[i]; dn[i] = dm[i]; an[i] = am[i]; }
+                mun = mum;
+                rsn = rsm;
+            }
         }
     }
 #pragma unroll
@@ -619,9 +630,15 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     auto *dxp = static_cast<uint16_t *>(dx);
     auto *ddp = static_cast<uint16_t *>(dx_drop);
     float *part = static_cast<float *>(ws);
-    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D);
-    else if (D <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D);
-    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D);
+    static const int ahead = [] { const char *e = getenv("SFCVIT_LN_AHEAD"); return e && e[0] == '1' ? 1 : 2; }();
+#define LN_BWD(VPL, ADD, AH) hipLaunchKernelGGL((ln_bwd_kernel<VPL, ADD, AH>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D)
+#define LN_BWD_V(VPL) do { if (ap) { if (ahead == 2) LN_BWD(VPL, true, 2); else LN_BWD(VPL, true, 1); }   \
+                           else { if (ahead == 2) LN_BWD(VPL, false, 2); else LN_BWD(VPL, false, 1); } } while (0)
+    if (D <= 512) LN_BWD_V(1);
+    else if (D <= 1024) LN_BWD_V(2);
+    else { if (ap) LN_BWD(4, true, 1); else LN_BWD(4, false, 1); }       // (VPL 4: two rows ahead would not fit 256 registers)
+#undef LN_BWD_V
+#undef LN_BWD
     if (int rc = check_launch("layernorm_bwd")) return rc;
     hipLaunchKernelGGL(ln_bwd_reduce, dim3((3 * D + 15) / 16), dim3(RED_THREADS), 0, s, part, dgamma, dbeta, dcol, nb, D, grads_bf16);
     return check_launch("layernorm_bwd_reduce");

@@ -95,6 +95,16 @@ SIDE_STREAM_WGRAD = _os.environ.get("SFCVIT_SIDE_STREAM", "0") == "1"
 USE_ACTMASK = _os.environ.get("SFCVIT_ACTMASK", "1") == "1"        # "0": linear2's dX reads the stored activation (A/B)
 
 
+def _ln_slots(w, b):
+    """grad_out for ops.layernorm_bwd: (dgamma slot, dbeta slot, None) when both parameters have one, else None."""
+    sw, sb = _slot(w), _slot(b)
+    return (sw, sb, None) if sw is not None and sb is not None else None
+
+
+def _ln_grads(dg, db, go):
+    return (dg, db) if go is not None else (dg.to(_BF16), db.to(_BF16))
+
+
 def _bgrad(dy2, b=None):
     out = _slot(b)
     return ops.colsum(dy2, out=out) if out is not None else ops.colsum(dy2).to(_BF16)
@@ -243,13 +253,15 @@ class _LayerNorm(Function):
         x2 = _c(x).view(-1, x.shape[-1])
         y, mean, rstd = ops.layernorm_fwd(x2, w, b, eps)
         ctx.save_for_backward(x2, mean, rstd, w)
+        ctx.small = (b,)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, mean, rstd, w = ctx.saved_tensors
-        dx, dg, db = ops.layernorm_bwd(_c(dy).view(-1, dy.shape[-1]), x2, mean, rstd, w)
-        return dx.view(dy.shape), dg.to(_BF16), db.to(_BF16), None
+        go = _ln_slots(w, ctx.small[0])
+        dx, dg, db = ops.layernorm_bwd(_c(dy).view(-1, dy.shape[-1]), x2, mean, rstd, w, grad_out=go)
+        return (dx.view(dy.shape), *_ln_grads(dg, db, go), None)
 
 
 def layer_norm(x, weight, bias, eps=1e-5):
@@ -364,21 +376,24 @@ class _Mixer(Function):
             h, u = ops.gemm(z, w1, bias=b1, act=ops.ACT_GELU, want_aux=True)
         y = ops.gemm(h, w2, bias=b2, residual=x2)
         ctx.save_for_backward(x2, mean, rstd, z, u, h, ln_w, w1, w2)
+        ctx.small = (ln_b, b1, b2)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, mean, rstd, z, u, h, ln_w, w1, w2 = ctx.saved_tensors
+        ln_b, b1, b2 = ctx.small
         dy2 = _c(dy).view(-1, dy.shape[-1])
-        dw2, db2 = _wgrad(dy2, h, w2), _bgrad(dy2)
+        dw2, db2 = _wgrad(dy2, h, w2), _bgrad(dy2, b2)
         if _fast_gemm_shape(dy2.shape[0], w2.shape[1], dy2.shape[1]):
             du = ops.gelu_bwd(ops.gemm_dx(dy2, w2), u)                     # as in forward: plain 8-phase GEMM + elementwise pass
         else:
             du = ops.gemm_dx(dy2, w2, aux_in=u, dact=ops.ACT_GELU)
-        dw1, db1 = _wgrad(du, z, w1), _bgrad(du)
+        dw1, db1 = _wgrad(du, z, w1), _bgrad(du, b1)
         dz = ops.gemm_dx(du, w1)
-        dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w, dx_add=dy2)
-        return dx.view(dy.shape), dg.to(_BF16), dbeta.to(_BF16), dw1, db1, dw2, db2, None
+        go = _ln_slots(ln_w, ln_b)
+        dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w, dx_add=dy2, grad_out=go)
+        return (dx.view(dy.shape), *_ln_grads(dg, dbeta, go), dw1, db1, dw2, db2, None)
 
 
 def mixer_block(x, ln_w, ln_b, w1, b1, w2, b2, eps=1e-5):
@@ -529,6 +544,7 @@ class _Head(Function):
         wc_p, bc_p = _pad_rows(wc, cpad), _pad_rows(bc, cpad)
         logits = ops.gemm(a, wc_p, bias=bc_p)                       # [B, cpad]
         ctx.save_for_backward(x2, mean, rstd, z, h, y1, a, ln_w, w_emb, w_seq, wc_p)
+        ctx.small = (ln_b, bc)
         ctx.dims = (B, N, D, R, O, C, cpad)
         ctx.p, ctx.seed = p, seed
         return logits[:, :C] if cpad != C else logits
@@ -537,19 +553,27 @@ class _Head(Function):
     def backward(ctx, dlogits):
         x2, mean, rstd, z, h, y1, a, ln_w, w_emb, w_seq, wc_p = ctx.saved_tensors
         B, N, D, R, O, C, cpad = ctx.dims
-        dl = torch.zeros((B, cpad), device=dlogits.device, dtype=_BF16)
-        dl[:, :C] = dlogits
-        dwc = ops.gemm(dl, a, a_kmajor=True, b_kmajor=True)[:C]
-        dbc = ops.colsum(dl)[:C].to(_BF16)
+        ln_b, bc = ctx.small
+        if cpad == C:                                   # (wc_p IS the classifier weight then: gradients straight into the slots)
+            dl = _c(dlogits)
+            dwc, dbc = _wgrad(dl, a, wc_p), _bgrad(dl, bc)
+        else:
+            dl = torch.zeros((B, cpad), device=dlogits.device, dtype=_BF16)
+            dl[:, :C] = dlogits
+            dwc = ops.gemm(dl, a, a_kmajor=True, b_kmajor=True)[:C]
+            dbc = ops.colsum(dl)[:C].to(_BF16)
         da = ops.gemm_dx(dl, wc_p)                      # [B, O]
         dy1 = ops.gelu_drop_bwd(da, y1, ctx.p, ctx.seed) if ctx.p > 0 else ops.gelu_bwd(da, y1)
         h2 = h.view(B, N * R)
-        dwseq = ops.gemm(dy1, h2, a_kmajor=True, b_kmajor=True).view(O, N, R)
+        sseq = _slot(w_seq)
+        dwseq = ops.gemm(dy1, h2, a_kmajor=True, b_kmajor=True, out=None if sseq is None else sseq.view(O, N * R))
+        dwseq = dwseq.view(O, N, R) if sseq is None else sseq
         dh = ops.gemm(dy1, w_seq.view(O, N * R), b_kmajor=True).view(B * N, R)
-        dwemb = _wgrad(dh, z)
+        dwemb = _wgrad(dh, z, w_emb)
         dz = ops.gemm_dx(dh, w_emb)
-        dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w)
-        return dx.view(B, N, D), dg.to(_BF16), dbeta.to(_BF16), dwemb, dwseq, dwc, dbc, None, None, None
+        go = _ln_slots(ln_w, ln_b)
+        dx, dg, dbeta = ops.layernorm_bwd(dz, x2, mean, rstd, ln_w, grad_out=go)
+        return (dx.view(B, N, D), *_ln_grads(dg, dbeta, go), dwemb, dwseq, dwc, dbc, None, None, None)
 
 
 def predictor_head(x, ln_w, ln_b, w_emb, w_seq, wc, bc, eps=1e-5, dropout_p=0.0):

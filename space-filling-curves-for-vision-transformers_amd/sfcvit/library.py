@@ -149,6 +149,7 @@ def mixer_block_bwd_op(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, z: Ten
                        w1: Tensor, w2: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
     ctx = _Ctx()
     ctx.saved_tensors = (F._c(x).view(-1, x.shape[-1]), mean, rstd, z, u, h, ln_w, w1, w2)
+    ctx.small = (None, None, None)                      # (no gradient slots inside a traced op: fresh tensors)
     with _no_slots():
         return tuple(F._Mixer.backward(ctx, dy)[:7])
 
@@ -288,6 +289,7 @@ def predictor_head_bwd_op(dlogits: Tensor, x: Tensor, saved: List[Tensor], weigh
     ctx = _Ctx()
     ctx.saved_tensors = (F._c(x).view(B * N, D), mean, rstd, z, h, y1, a, ln_w, w_emb, w_seq, wc_p)
     ctx.dims = (B, N, D, w_emb.shape[0], w_seq.shape[0], n_classes, wc_p.shape[0])
+    ctx.small = (None, None)
     ctx.p, ctx.seed = p, (int(seed_t.item()) if p > 0 else 0)
     with _no_slots():
         g = F._Head.backward(ctx, dlogits)[:7]
