@@ -84,7 +84,7 @@ __global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const uint16_t *__restr
 // columns of dgamma / dbeta in registers, and the block writes one partial row
 // [2][D] to the workspace; ln_bwd_reduce sums the partials.
 // ---------------------------------------------------------------------------
-template <int VPL, bool ADD, int AHEAD>
+template <int VPL, bool ADD>
 __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
                                                          const float *__restrict__ mean, const float *__restrict__ rstd,
                                                          const uint16_t *__restrict__ gamma,
@@ -107,12 +107,12 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
 #pragma unroll
         for (int j = 0; j < 8; j++) dg[i][j] = db[i][j] = dc[i][j] = 0.f;
     }
-    // Rows are software-pipelined: the loads of this wave's next AHEAD rows are issued before the current row is reduced
+    // Rows are software-pipelined: the loads of this wave's next row are issued before the current row is reduced
     // (a row is load -> two wave reductions -> store, and only 8 waves per CU are resident: without the prefetch
-    // the kernel sat at 2.7-3.3 TB/s, latency- not bandwidth-bound; one row ahead keeps 24 KB per CU in flight, two 36 KB).
+    // the kernel sat at 2.7-3.3 TB/s).  Two rows ahead measured slower (54.6 vs 51.3 us at M 50 176, D 768).
     const int stride = gridDim.x * WAVES;
-    u32x4 xr[VPL], dr[VPL], ar[VPL], xn[VPL], dn[VPL], an[VPL], xm[VPL], dm[VPL], am[VPL];
-    float mu = 0.f, rs = 0.f, mun = 0.f, rsn = 0.f, mum = 0.f, rsm = 0.f;
+    u32x4 xr[VPL], dr[VPL], ar[VPL], xn[VPL], dn[VPL], an[VPL];
+    float mu = 0.f, rs = 0.f, mun = 0.f, rsn = 0.f;
     auto load_row = [&](int row, u32x4 (&xq)[VPL], u32x4 (&dq)[VPL], u32x4 (&aq)[VPL], float &m, float &r) __attribute__((always_inline)) {
         m = mean[row];
         r = rstd[row];
@@ -128,14 +128,9 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
     };
     int row = blockIdx.x * WAVES + wave;
     if (row < M) load_row(row, xr, dr, ar, mu, rs);
-    if (AHEAD == 2 && row + stride < M) load_row(row + stride, xn, dn, an, mun, rsn);
     for (; row < M; row += stride) {
         const bool more = row + stride < M;
-        if (AHEAD == 2) {
-            if (row + 2 * stride < M) load_row(row + 2 * stride, xm, dm, am, mum, rsm);
-        } else if (more) {
-            load_row(row + stride, xn, dn, an, mun, rsn);
-        }
+        if (more) load_row(row + stride, xn, dn, an, mun, rsn);
         float xh[VPL][8], gy[VPL][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -195,12 +190,6 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
             for (int i = 0; i < VPL; i++) { xr[i] = xn[i]; dr[i] = dn[i]; ar[i] = an[i]; }
             mu = mun;
             rs = rsn;
-            if (AHEAD == 2) {
-#pragma unroll
-                for (int i = 0; i < VPL; i++) { xn[i] = xm[i]; dn[i] = dm[i]; an[i] = am[i]; }
-                mun = mum;
-                rsn = rsm;
-            }
         }
     }
 #pragma unroll
@@ -214,6 +203,122 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const uint16_t *__restr
                 red[(wave * 3 + 2) * D + c * 8 + j] = dc[i][j];
             }
         }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 3 * D; c += THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) s += red[w * 3 * D + c];
+        partial[size_t(blockIdx.x) * 3 * D + c] = s;
+    }
+}
+
+// The same for D = 256 CH with CH odd (ViT-B: 768 = 3 x 256), where the 16-byte-vector form above leaves a quarter of the
+// lanes idle in its second vector.  Measured (tools/bench_rowwise.py, M 50 176): that kernel issues ~450 VALU instructions
+// per row and wave -- 49 rows per SIMD x 450 x 4 clocks = 46 us of its 51-66 us: it is VALU-bound, not HBM-bound (two rows
+// of prefetch, or three waves per SIMD from a register diet, made it slower).  Here a lane owns CH chunks of 4 columns
+// (8-byte loads, every lane busy) and all arithmetic is written on float pairs (v_pk_* instructions, no shuffles).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 unpack2(uint32_t w) { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+
+template <int CH, bool ADD>
+__global__ __launch_bounds__(THREADS) void ln_bwd_cols_kernel(const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                              const uint16_t *__restrict__ gamma,
+                                                              const uint16_t *__restrict__ dx_add, uint16_t *__restrict__ dx,
+                                                              uint16_t *__restrict__ dx_drop, float drop_p, uint32_t drop_seed_arg,
+                                                              const uint32_t *__restrict__ seed_off,
+                                                              float *__restrict__ partial, int M) {
+    constexpr int D = 256 * CH;
+    const uint32_t drop_seed = eff_seed(drop_seed_arg, seed_off);
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [WAVES][3][D] fp32
+    const uint32_t drop_th = drop_thresh(drop_p);
+    const float drop_sc = 1.f / (1.f - drop_p);
+    float *red = reinterpret_cast<float *>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // lane's columns: 256 k + 4 lane + 2 h + {0, 1}, k < CH, h < 2
+    f32x2 g[CH][2], dg[CH][2], db[CH][2], dc[CH][2];
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const u32x2 w = *reinterpret_cast<const u32x2 *>(gamma + 256 * k + 4 * lane);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            g[k][h] = unpack2(w[h]);
+            dg[k][h] = db[k][h] = dc[k][h] = f32x2{0.f, 0.f};
+        }
+    }
+    const int stride = gridDim.x * WAVES;
+    u32x2 xr[CH], dr[CH], ar[CH], xn[CH], dn[CH], an[CH];
+    float mu = 0.f, rs = 0.f, mun = 0.f, rsn = 0.f;
+    auto load_row = [&](int row, u32x2 (&xq)[CH], u32x2 (&dq)[CH], u32x2 (&aq)[CH], float &m, float &r) __attribute__((always_inline)) {
+        m = mean[row];
+        r = rstd[row];
+        const size_t o = size_t(row) * D + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            xq[k] = *reinterpret_cast<const u32x2 *>(x + o + 256 * k);
+            dq[k] = *reinterpret_cast<const u32x2 *>(dy + o + 256 * k);
+            if (ADD) aq[k] = *reinterpret_cast<const u32x2 *>(dx_add + o + 256 * k);
+        }
+    };
+    int row = blockIdx.x * WAVES + wave;
+    if (row < M) load_row(row, xr, dr, ar, mu, rs);
+    for (; row < M; row += stride) {
+        const bool more = row + stride < M;
+        if (more) load_row(row + stride, xn, dn, an, mun, rsn);   // the next row's loads fly while this one is reduced
+        f32x2 xh[CH][2], gy[CH][2];
+        f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const f32x2 xv = unpack2(xr[k][h]), dv = unpack2(dr[k][h]);
+                xh[k][h] = (xv - mu) * rs;
+                gy[k][h] = dv * g[k][h];
+                s1 += gy[k][h];
+                s2 += gy[k][h] * xh[k][h];
+                dg[k][h] += dv * xh[k][h];
+                db[k][h] += dv;
+            }
+        }
+        const float c1 = wave_sum(s1[0] + s1[1]) / float(D), c2 = wave_sum(s2[0] + s2[1]) / float(D);
+        const size_t o = size_t(row) * D + 4 * lane;
+        const uint32_t rk = drop_row_key(drop_seed, uint64_t(row));
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            f32x2 ov[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                ov[h] = rs * (gy[k][h] - c1 - xh[k][h] * c2);
+                if (ADD) ov[h] += unpack2(ar[k][h]);
+            }
+            *reinterpret_cast<u32x2 *>(dx + o + 256 * k) = u32x2{pack2bf(ov[0][0], ov[0][1]), pack2bf(ov[1][0], ov[1][1])};
+            if (dx_drop) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    bool k0, k1;
+                    drop_keep2(rk, uint32_t(128 * k + 2 * lane + h), drop_th, k0, k1);      // pair = column / 2
+                    ov[h][0] = k0 ? ov[h][0] * drop_sc : 0.f;
+                    ov[h][1] = k1 ? ov[h][1] * drop_sc : 0.f;
+                }
+                *reinterpret_cast<u32x2 *>(dx_drop + o + 256 * k) = u32x2{pack2bf(ov[0][0], ov[0][1]), pack2bf(ov[1][0], ov[1][1])};
+            }
+            dc[k][0] += ov[0];
+            dc[k][1] += ov[1];
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) { xr[k] = xn[k]; dr[k] = dn[k]; ar[k] = an[k]; }
+            mu = mun;
+            rs = rsn;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int c = 256 * k + 4 * lane;
+        *reinterpret_cast<f32x4 *>(red + (wave * 3 + 0) * D + c) = f32x4{dg[k][0][0], dg[k][0][1], dg[k][1][0], dg[k][1][1]};
+        *reinterpret_cast<f32x4 *>(red + (wave * 3 + 1) * D + c) = f32x4{db[k][0][0], db[k][0][1], db[k][1][0], db[k][1][1]};
+        *reinterpret_cast<f32x4 *>(red + (wave * 3 + 2) * D + c) = f32x4{dc[k][0][0], dc[k][0][1], dc[k][1][0], dc[k][1][1]};
     }
     __syncthreads();
     for (int c = threadIdx.x; c < 3 * D; c += THREADS) {
@@ -274,14 +379,19 @@ __global__ __launch_bounds__(RED_THREADS) void ln_bwd_reduce(const float *__rest
     }
 }
 
-int ln_bwd_blocks(int M) {
+// SFCVIT_LN_COLS=0: the 16-byte-vector kernel also at D = 768 (A/B in tools/bench_rowwise.py)
+bool ln_bwd_cols(int D) {
+    static const bool on = [] { const char *e = getenv("SFCVIT_LN_COLS"); return !(e && e[0] == '0'); }();
+    return on && D == 768;
+}
+
+// Workgroups of the backward kernel: two (16-byte-vector kernel, 190-222 registers) or three (column-chunk kernel, 145-156)
+// resident waves per SIMD.  Measured at M 50 176, D 768: 52.1 / 56.4 us with 512 / 768 workgroups of the former, 47.5 / 45.8
+// of the latter (with dropout output and column sums 70.3 / 77.2 and 59.0 / 57.3).
+int ln_bwd_blocks(int M, int D) {
     const int want = (M + WAVES - 1) / WAVES;
-    static int cap = 0;
-    if (!cap) {
-        const char *e = getenv("SFCVIT_LN_BLOCKS");       // tuning knob (tools/bench_rowwise.py); default below
-        cap = e ? atoi(e) : 512;
-        if (cap < 1) cap = 512;
-    }
+    static const int env = [] { const char *e = getenv("SFCVIT_LN_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning knob
+    const int cap = env > 0 ? env : (ln_bwd_cols(D) ? 768 : 512);
     return want < cap ? want : cap;
 }
 
@@ -524,6 +634,7 @@ __device__ __forceinline__ void adamw_one(float &w, float &m, float &v, float gr
     w -= (a.lr / bc1) * (m / denom);
 }
 
+template <int NT>      // bit 0: non-temporal loads, bit 1: non-temporal stores of the fp32 state
 __global__ __launch_bounds__(THREADS) void adamw_kernel(sfcvit_adamw_args a, float bc1, float rbc2) {
     if (a.dev_state) {            // learning rate and bias corrections of THIS step from the device (sfcvit_step_advance)
         a.lr = a.dev_state[2];
@@ -537,40 +648,68 @@ __global__ __launch_bounds__(THREADS) void adamw_kernel(sfcvit_adamw_args a, flo
     }
     uint16_t *p = static_cast<uint16_t *>(a.param);
     const uint16_t *g = static_cast<const uint16_t *>(a.grad);
-    const int64_t nvec = a.n >> 3;
-    for (int64_t i = blockIdx.x * int64_t(THREADS) + threadIdx.x; i < nvec; i += int64_t(gridDim.x) * THREADS) {
-        float gr[8], w[8], m[8], v[8];
-        unpack8(reinterpret_cast<const u32x4 *>(g)[i], gr);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const f32x4 wv = reinterpret_cast<const f32x4 *>(a.master)[2 * i + h];
-            const f32x4 mv = reinterpret_cast<const f32x4 *>(a.m)[2 * i + h];
-            const f32x4 vv = reinterpret_cast<const f32x4 *>(a.v)[2 * i + h];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                w[4 * h + j] = wv[j];
-                m[4 * h + j] = mv[j];
-                v[4 * h + j] = vv[j];
-            }
+    // A lane owns groups of FOUR parameters: one 8-byte load of the bf16 gradient and one 16-byte load of each fp32 buffer,
+    // so that every wave instruction covers one contiguous 512-byte / 1-KiB span (with eight parameters per lane the fp32
+    // loads were two 16-byte halves at a 32-byte lane stride: half-used lines per instruction, 4.0 TB/s; tools/bench_adamw.py).
+    // Two groups per iteration keep 2 x 56 bytes per lane in flight.
+    const int64_t nq = a.n >> 2, step = int64_t(gridDim.x) * THREADS;
+    auto load = [&](int64_t i, u32x2 &gq, f32x4 &wv, f32x4 &mv, f32x4 &vv) __attribute__((always_inline)) {
+        if (NT & 1) {                                               // every byte is touched once per step
+            gq = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(g) + i);
+            wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.master) + i);
+            mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.m) + i);
+            vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.v) + i);
+        } else {
+            gq = reinterpret_cast<const u32x2 *>(g)[i];
+            wv = reinterpret_cast<const f32x4 *>(a.master)[i];
+            mv = reinterpret_cast<const f32x4 *>(a.m)[i];
+            vv = reinterpret_cast<const f32x4 *>(a.v)[i];
         }
+    };
+    auto update = [&](int64_t i, const u32x2 &gq, f32x4 wv, f32x4 mv, f32x4 vv) __attribute__((always_inline)) {
+        const float gr[4] = {bf2f(uint16_t(gq[0])), bf2f(uint16_t(gq[0] >> 16)), bf2f(uint16_t(gq[1])), bf2f(uint16_t(gq[1] >> 16))};
+        float w[4], m[4], v[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) adamw_one(w[j], m[j], v[j], gr[j] * gmul, a, bc1, rbc2);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            reinterpret_cast<f32x4 *>(a.master)[2 * i + h] = f32x4{w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
-            reinterpret_cast<f32x4 *>(a.m)[2 * i + h] = f32x4{m[4 * h], m[4 * h + 1], m[4 * h + 2], m[4 * h + 3]};
-            reinterpret_cast<f32x4 *>(a.v)[2 * i + h] = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+        for (int j = 0; j < 4; j++) {
+            w[j] = wv[j];
+            m[j] = mv[j];
+            v[j] = vv[j];
+            adamw_one(w[j], m[j], v[j], gr[j] * gmul, a, bc1, rbc2);
         }
-        reinterpret_cast<u32x4 *>(p)[i] = pack8(w);
+        if (NT & 2) {
+            __builtin_nontemporal_store(f32x4{w[0], w[1], w[2], w[3]}, reinterpret_cast<f32x4 *>(a.master) + i);
+            __builtin_nontemporal_store(f32x4{m[0], m[1], m[2], m[3]}, reinterpret_cast<f32x4 *>(a.m) + i);
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4 *>(a.v) + i);
+        } else {
+            reinterpret_cast<f32x4 *>(a.master)[i] = f32x4{w[0], w[1], w[2], w[3]};
+            reinterpret_cast<f32x4 *>(a.m)[i] = f32x4{m[0], m[1], m[2], m[3]};
+            reinterpret_cast<f32x4 *>(a.v)[i] = f32x4{v[0], v[1], v[2], v[3]};
+        }
+        reinterpret_cast<u32x2 *>(p)[i] = u32x2{pack2bf(w[0], w[1]), pack2bf(w[2], w[3])};   // (the next forward reads these)
+    };
+    int64_t i = blockIdx.x * int64_t(THREADS) + threadIdx.x;
+    for (; i + step < nq; i += 2 * step) {
+        u32x2 g0, g1;
+        f32x4 w0, m0, v0, w1, m1, v1;
+        load(i, g0, w0, m0, v0);
+        load(i + step, g1, w1, m1, v1);
+        update(i, g0, w0, m0, v0);
+        update(i + step, g1, w1, m1, v1);
     }
-    if (blockIdx.x == 0 && threadIdx.x < int(a.n & 7)) {
-        const int64_t i = (nvec << 3) + threadIdx.x;
-        float w = a.master[i], m = a.m[i], v = a.v[i];
-        adamw_one(w, m, v, bf2f(g[i]) * gmul, a, bc1, rbc2);
-        a.master[i] = w;
-        a.m[i] = m;
-        a.v[i] = v;
-        p[i] = f2bf(w);
+    if (i < nq) {
+        u32x2 g0;
+        f32x4 w0, m0, v0;
+        load(i, g0, w0, m0, v0);
+        update(i, g0, w0, m0, v0);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < int(a.n & 3)) {
+        const int64_t t = (nq << 2) + threadIdx.x;
+        float w = a.master[t], m = a.m[t], v = a.v[t];
+        adamw_one(w, m, v, bf2f(g[t]) * gmul, a, bc1, rbc2);
+        a.master[t] = w;
+        a.m[t] = m;
+        a.v[t] = v;
+        p[t] = f2bf(w);
     }
 }
 
@@ -605,7 +744,7 @@ extern "C" int sfcvit_layernorm_fwd(const void *x, const void *gamma, const void
 
 extern "C" int64_t sfcvit_layernorm_bwd_ws(int M, int D) {
     if (M <= 0 || D <= 0) return 0;
-    return int64_t(ln_bwd_blocks(M)) * 3 * D * int64_t(sizeof(float));
+    return int64_t(ln_bwd_blocks(M, D)) * 3 * D * int64_t(sizeof(float));
 }
 
 extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, const float *rstd,
@@ -620,7 +759,7 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
         return fail(SFCVIT_EINVAL, "layernorm_bwd: alignment");
     if (dx_drop && !(p >= 0.f && p < 1.f)) return fail(SFCVIT_EINVAL, "layernorm_bwd: dropout p=%g", p);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nb = ln_bwd_blocks(M);
+    const int nb = ln_bwd_blocks(M, D);
     dim3 grid(nb), block(THREADS);
     const size_t lds = size_t(WAVES) * 3 * D * sizeof(float);
     const auto *dyp = static_cast<const uint16_t *>(dy);
@@ -630,14 +769,14 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     auto *dxp = static_cast<uint16_t *>(dx);
     auto *ddp = static_cast<uint16_t *>(dx_drop);
     float *part = static_cast<float *>(ws);
-    static const int ahead = [] { const char *e = getenv("SFCVIT_LN_AHEAD"); return e && e[0] == '1' ? 1 : 2; }();
-#define LN_BWD(VPL, ADD, AH) hipLaunchKernelGGL((ln_bwd_kernel<VPL, ADD, AH>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D)
-#define LN_BWD_V(VPL) do { if (ap) { if (ahead == 2) LN_BWD(VPL, true, 2); else LN_BWD(VPL, true, 1); }   \
-                           else { if (ahead == 2) LN_BWD(VPL, false, 2); else LN_BWD(VPL, false, 1); } } while (0)
-    if (D <= 512) LN_BWD_V(1);
-    else if (D <= 1024) LN_BWD_V(2);
-    else { if (ap) LN_BWD(4, true, 1); else LN_BWD(4, false, 1); }       // (VPL 4: two rows ahead would not fit 256 registers)
-#undef LN_BWD_V
+#define LN_BWD(VPL) do { if (ap) hipLaunchKernelGGL((ln_bwd_kernel<VPL, true>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D); \
+                         else hipLaunchKernelGGL((ln_bwd_kernel<VPL, false>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D); } while (0)
+    if (ln_bwd_cols(D)) {
+        if (ap) hipLaunchKernelGGL((ln_bwd_cols_kernel<3, true>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M);
+        else hipLaunchKernelGGL((ln_bwd_cols_kernel<3, false>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M);
+    } else if (D <= 512) LN_BWD(1);
+    else if (D <= 1024) LN_BWD(2);
+    else LN_BWD(4);
 #undef LN_BWD
     if (int rc = check_launch("layernorm_bwd")) return rc;
     hipLaunchKernelGGL(ln_bwd_reduce, dim3((3 * D + 15) / 16), dim3(RED_THREADS), 0, s, part, dgamma, dbeta, dcol, nb, D, grads_bf16);
@@ -782,8 +921,10 @@ extern "C" int sfcvit_adamw_step(const sfcvit_adamw_args *a, void *stream) {
     const float bc2 = 1.f - powf(a->beta2, float(a->step));
     if (!aligned16(a->param) || !aligned16(a->master) || !aligned16(a->grad) || !aligned16(a->m) || !aligned16(a->v))
         return fail(SFCVIT_EINVAL, "adamw: buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((a->n + 7) / 8)), dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a, bc1,
-                       1.f / sqrtf(bc2));
+    static const int nt = [] { const char *e = getenv("SFCVIT_ADAMW_NT"); return e ? atoi(e) & 3 : 3; }();
+#define ADAMW(NT) hipLaunchKernelGGL(adamw_kernel<NT>, dim3(grid_for((a->n + 7) / 8)), dim3(THREADS), 0, static_cast<hipStream_t>(stream), *a, bc1, 1.f / sqrtf(bc2))
+    if (nt == 3) ADAMW(3); else if (nt == 2) ADAMW(2); else if (nt == 1) ADAMW(1); else ADAMW(0);
+#undef ADAMW
     return check_launch("adamw");
 }
 
