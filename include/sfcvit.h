@@ -226,6 +226,16 @@ int64_t sfcvit_gemm_workspace(int M, int N, int splitk);
  * step lets dX = dY W run with both operands k-contiguous (sfcvit_gemm's fastest layout). */
 int sfcvit_transpose(const void *src, int R, int C, int lds, void *dst, int ldd, void *stream);
 
+/* The same for many contiguous matrices in ONE launch (every weight of a model at the start of its backward pass: 51 launches
+ * of 5 us become one).  `tiles` is a DEVICE array with one entry per 64 x 64 tile; matrix i occupies src_base + src_off
+ * elements as [R, C] and its transpose dst_base + dst_off as [C, R]; R and C multiples of 8, offsets multiples of 8. */
+typedef struct sfcvit_transpose_tile {
+    int64_t src_off, dst_off;   /* in bf16 elements */
+    int32_t R, C;               /* the matrix this tile belongs to */
+    int32_t r0, c0;             /* first row / column of the tile */
+} sfcvit_transpose_tile;
+int sfcvit_transpose_batched(const void *src_base, void *dst_base, const sfcvit_transpose_tile *tiles, int n_tiles, void *stream);
+
 /* Column sums: out[n] = sum_m x[m, n] (bias gradients). x bf16 [M, ld]; out fp32 [N] (overwritten).
  * Two passes through `workspace` (sfcvit_colsum_workspace bytes, HOST query) instead of float atomics, so the
  * result is bit-reproducible from run to run. */

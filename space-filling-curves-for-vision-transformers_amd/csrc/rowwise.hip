@@ -469,6 +469,38 @@ __global__ __launch_bounds__(THREADS) void transpose_kernel(const uint16_t *__re
     }
 }
 
+// One launch for many matrices: a workgroup looks its 64 x 64 tile up in a device table (sfcvit_transpose_batched).
+__global__ __launch_bounds__(THREADS) void transpose_batched_kernel(const uint16_t *__restrict__ src_base, uint16_t *__restrict__ dst_base,
+                                                                    const sfcvit_transpose_tile *__restrict__ tiles) {
+    __shared__ uint16_t tile[64][66];
+    const sfcvit_transpose_tile d = tiles[blockIdx.x];
+    const uint16_t *src = src_base + d.src_off;
+    uint16_t *dst = dst_base + d.dst_off;
+    const int R = d.R, C = d.C, r0 = d.r0, c0 = d.c0, t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int v = t + THREADS * i, r = v >> 3, cv = (v & 7) * 8;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (r0 + r < R && c0 + cv < C) val = *reinterpret_cast<const u32x4 *>(src + size_t(r0 + r) * C + c0 + cv);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            tile[r][cv + 2 * j] = uint16_t(val[j]);
+            tile[r][cv + 2 * j + 1] = uint16_t(val[j] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int v = t + THREADS * i, c = v >> 3, rv = (v & 7) * 8;
+        if (c0 + c < C && r0 + rv < R) {
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = uint32_t(tile[rv + 2 * j][c]) | (uint32_t(tile[rv + 2 * j + 1][c]) << 16);
+            *reinterpret_cast<u32x4 *>(dst + size_t(c0 + c) * R + r0 + rv) = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // GELU (erf form)
 // ---------------------------------------------------------------------------
@@ -842,6 +874,15 @@ extern "C" int sfcvit_transpose(const void *src, int R, int C, int lds, void *ds
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(THREADS), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint16_t *>(src), R, C, lds, static_cast<uint16_t *>(dst), ldd);
     return check_launch("transpose");
+}
+
+extern "C" int sfcvit_transpose_batched(const void *src_base, void *dst_base, const sfcvit_transpose_tile *tiles, int n_tiles,
+                                        void *stream) {
+    if (!src_base || !dst_base || !tiles || n_tiles <= 0) return fail(SFCVIT_EINVAL, "transpose_batched: null pointer or no tiles");
+    if (!aligned16(src_base) || !aligned16(dst_base)) return fail(SFCVIT_EINVAL, "transpose_batched: alignment");
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(n_tiles), dim3(THREADS), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(src_base), static_cast<uint16_t *>(dst_base), tiles);
+    return check_launch("transpose_batched");
 }
 
 extern "C" int sfcvit_gelu_fwd(const void *x, void *y, int64_t n, void *stream) {

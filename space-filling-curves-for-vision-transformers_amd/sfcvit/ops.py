@@ -264,6 +264,16 @@ def transpose(x):
     return out
 
 
+def transpose_batched(src_flat, dst_flat, tiles, n_tiles):
+    """Every matrix of a flat bf16 buffer transposed in one launch; `tiles` = device uint8 tensor holding n_tiles
+    sfcvit_transpose_tile records (FlatGradBuffer.transposed)."""
+    _need(src_flat, _BF16, "transpose_batched src", 1)
+    _need(dst_flat, _BF16, "transpose_batched dst", 1)
+    if tiles.dtype != torch.uint8 or not tiles.is_cuda or tiles.numel() != 32 * n_tiles:
+        raise ValueError("transpose_batched tiles: device uint8 tensor of 32 bytes per tile expected")
+    check(lib.sfcvit_transpose_batched(_p(src_flat), _p(dst_flat), _p(tiles), n_tiles, _stream()), "sfcvit_transpose_batched")
+
+
 def gemm_dx(dy, w, **kw):
     """dX[M, in] = dY[M, out] . W[out, in] (+ epilogue).  When the shape is eligible for the LDS-DMA
     kernel, W is transposed once (a few MB) so that both operands are k-contiguous; otherwise W is
@@ -273,7 +283,9 @@ def gemm_dx(dy, w, **kw):
     # the persistent 8-phase kernel takes any M >= 192 (a last row tile that overlaps its predecessor); the LDS-DMA
     # ring kernel before it needs whole 256-row tiles
     if N % 128 == 0 and K % 32 == 0 and (M % 256 == 0 or (M >= 192 and N % 256 == 0 and K % 128 == 0 and K >= 256)):
-        return gemm(dy, transpose(w), **kw)
+        slot = getattr(w, "_sfcvit_slot", None)          # a parameter of a flat buffer: W^T from this backward pass's batch
+        wt = slot[0].transposed(w) if slot is not None else None
+        return gemm(dy, wt if wt is not None else transpose(w), **kw)
     return gemm(dy, w, b_kmajor=True, **kw)
 
 

@@ -13,6 +13,10 @@ import torch
 from .. import ops
 
 
+import os as _os
+_WT_CACHE = _os.environ.get("SFCVIT_WT_CACHE", "1") != "0"
+
+
 class FlatGradBuffer:
     """Parameters and gradients of a model as views into two flat buffers (device- and
     dtype-agnostic torch plumbing; FusedAdamW adds the HIP step on top).
@@ -28,6 +32,7 @@ class FlatGradBuffer:
         self.active = None                      # parameters that receive gradients, flat order
         self.offsets = None
         self.epoch = 0                          # bumped by zero_grad: one in-place gradient write per parameter and step
+        self._wt = None                         # transposed(): (flat buffer of W^T, tile table, {id(p): view}, graph task id)
 
     def _check(self, p):
         pass
@@ -61,6 +66,47 @@ class FlatGradBuffer:
 
     def _built(self):
         pass
+
+    def transposed(self, p):
+        """W^T (contiguous [in, out]) of weight `p` for the dX GEMM of the running backward pass, or None.
+
+        The dX GEMMs want both operands k-contiguous, i.e. a transposed copy of the weight: 51 launches of 5 us per
+        ViT-B step when every GEMM makes its own (0.26 ms).  Here the first request inside a backward pass transposes EVERY
+        2-D weight of the flat buffer in one launch (sfcvit_transpose_batched, 218 MB each way at ViT-B); the copies are
+        valid for that backward pass only -- keyed by autograd's graph-task id, inside which the weights cannot change --
+        so there is no invalidation rule to get wrong.  Outside a backward pass, for parameters outside the flat buffer,
+        or with SFCVIT_WT_CACHE=0: None (the caller transposes by itself)."""
+        task = torch._C._current_graph_task_id()
+        if task < 0 or self.flat_param is None or not self.flat_param.is_cuda or not _WT_CACHE:
+            return None
+        if self._wt is None:
+            import numpy as np
+            mats, off = [], 0
+            for q, o in zip(self.active, self.offsets):
+                if q.dim() == 2 and q.shape[0] % 8 == 0 and q.shape[1] % 8 == 0 and q.shape[0] >= 64 and q.shape[1] >= 64:
+                    mats.append((q, o, off))
+                    off += q.numel()
+            if not mats:
+                self._wt = (None, None, {}, -1)
+                return None
+            rows = []
+            for q, o, d in mats:
+                R, C = q.shape
+                rows += [(o, d, R, C, r0, c0) for r0 in range(0, R, 64) for c0 in range(0, C, 64)]
+            table = np.array(rows, dtype=np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("R", "<i4"), ("C", "<i4"),
+                                                   ("r0", "<i4"), ("c0", "<i4")]))          # sfcvit_transpose_tile
+            flat = torch.empty(off, device=self.flat_param.device, dtype=self.flat_param.dtype)
+            tiles = torch.from_numpy(table.view(np.uint8).copy()).to(self.flat_param.device)
+            views = {id(q): flat[d:d + q.numel()].view(q.shape[1], q.shape[0]) for q, o, d in mats}
+            self._wt = [flat, (tiles, len(rows)), views, -1]
+        flat, tiles, views, have = self._wt
+        v = views.get(id(p))
+        if v is None:
+            return None
+        if have != task:
+            ops.transpose_batched(self.flat_param, flat, tiles[0], tiles[1])
+            self._wt[3] = task
+        return v
 
     def grad_views(self):
         """[(offset, numel, parameter)] in flat order (used by the data-parallel reducer)."""

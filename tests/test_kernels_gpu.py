@@ -804,3 +804,26 @@ def test_patch_embed_tiled_backward(ops, curve, img, D, B, xdt):
     close(dw, ref, rel=1 / 200, abs_scale=1 / 200)
     dw2, _ = ops.patch_embed_bwd(x, pix, dy, D, True, desc)
     assert torch.equal(dw, dw2)
+
+
+def test_transpose_batched_matches_torch(ops):
+    """sfcvit_transpose_batched: matrices of mixed shapes (edges that are not multiples of the 64 x 64 tile) packed in one
+    flat buffer, one launch, against torch's .t()."""
+    import numpy as np
+    shapes = [(768, 256), (64, 64), (136, 72), (8, 200), (256, 1032)]
+    g = torch.Generator(device="cuda").manual_seed(2)
+    mats = [torch.randn(r, c, device="cuda", generator=g).to(torch.bfloat16) for r, c in shapes]
+    offs, off = [], 0
+    for m in mats:
+        offs.append(off)
+        off += (m.numel() + 7) // 8 * 8
+    src = torch.zeros(off, device="cuda", dtype=torch.bfloat16)
+    for m, o in zip(mats, offs):
+        src[o:o + m.numel()] = m.flatten()
+    dst = torch.full((off,), -1.0, device="cuda", dtype=torch.bfloat16)
+    rows = [(o, o, r, c, r0, c0) for (r, c), o in zip(shapes, offs) for r0 in range(0, r, 64) for c0 in range(0, c, 64)]
+    table = np.array(rows, dtype=np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("R", "<i4"), ("C", "<i4"), ("r0", "<i4"), ("c0", "<i4")]))
+    tiles = torch.from_numpy(table.view(np.uint8).copy()).cuda()
+    ops.transpose_batched(src, dst, tiles, len(rows))
+    for m, o in zip(mats, offs):
+        assert torch.equal(dst[o:o + m.numel()].view(m.shape[1], m.shape[0]), m.t().contiguous())

@@ -540,6 +540,43 @@ def test_train_step_variants_are_bit_identical():
             assert torch.equal(other[2][k], base[2][k]), k
 
 
+def test_weight_transposes_of_a_backward_pass_come_from_one_launch():
+    """The dX GEMMs read W^T.  Inside a backward pass the first request transposes every 2-D weight of the flat buffer
+    in ONE launch (FlatGradBuffer.transposed, keyed by autograd's graph-task id); per-GEMM transposes are the fallback
+    (SFCVIT_WT_CACHE=0, parameters outside a flat buffer, the first step).  Both must train bit-identically."""
+    import sfcvit.training.optim as optim
+    from sfcvit import ops
+    from sfcvit.models import VisionTransformer1D
+    from sfcvit.tokenizers import HilbertEmbedding1D
+    from sfcvit.training import FusedAdamW, mixup_soft_targets, train_step
+
+    def run(cache):
+        optim._WT_CACHE = cache
+        calls = {"single": 0, "batched": 0}
+        single, batched = ops.transpose, ops.transpose_batched
+        ops.transpose = lambda x: (calls.__setitem__("single", calls["single"] + 1), single(x))[1]
+        ops.transpose_batched = lambda *a: (calls.__setitem__("batched", calls["batched"] + 1), batched(*a))[1]
+        try:
+            torch.manual_seed(11)
+            model = VisionTransformer1D(HilbertEmbedding1D(32, 16, 3, 256), depth=2, n_heads=4, mlp_dim=512, num_classes=16,
+                                        dropout_p=0.1, head_dropout_p=0.5).to("cuda", dtype=torch.bfloat16).train()
+            opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=5e-5, max_grad_norm=1.0)
+            g = torch.Generator(device="cuda").manual_seed(5)
+            x = torch.randn(8, 3, 32, 32, device="cuda", generator=g)
+            t = mixup_soft_targets(torch.randint(0, 16, (8,), device="cuda", generator=g), 16, lam=0.7)
+            losses = [float(train_step(model, x, t, opt)) for _ in range(3)]
+            return losses, opt.master.clone(), calls
+        finally:
+            ops.transpose, ops.transpose_batched = single, batched
+            optim._WT_CACHE = True
+    l1, m1, c1 = run(True)
+    l0, m0, c0 = run(False)
+    assert c0["batched"] == 0 and c0["single"] > 0
+    # step 1 builds the flat buffers in optimizer.step(), i.e. after its backward: steps 2 and 3 use the batch
+    assert c1["batched"] == 2 and c1["single"] == c0["single"] // 3, (c1, c0)
+    assert l1 == l0 and torch.equal(m1, m0)
+
+
 def test_shared_parameter_gradient_accumulates_once_per_use():
     """A weight used twice in one backward: the first use may claim the in-place gradient slot, the second must be
     ADDED by autograd (functional._slot hands the slot out once per zero_grad epoch)."""
