@@ -236,6 +236,18 @@ typedef struct sfcvit_transpose_tile {
 } sfcvit_transpose_tile;
 int sfcvit_transpose_batched(const void *src_base, void *dst_base, const sfcvit_transpose_tile *tiles, int n_tiles, void *stream);
 
+/* Deferred partial-sum reductions.  Every column-sum-like result of this library (sfcvit_colsum, the bias sums of
+ * sfcvit_gemm / sfcvit_attention_bwd, dgamma / dbeta / column sums of sfcvit_layernorm_bwd) is a main kernel that writes
+ * fp32 partial rows into the caller's workspace and a small fixed-order reduction over them.  While deferral is on
+ * (process-wide switch), calls queue that reduction instead of launching it; sfcvit_reduce_flush launches everything
+ * queued as ONE kernel on `stream` (which must be the stream the calls used).  The caller keeps the workspaces and the
+ * outputs alive and unread until the flush.  sfcvit_reduce_defer returns the previous setting; _pending the queue length;
+ * _discard empties the queue without launching (after an aborted pass). */
+int sfcvit_reduce_defer(int on);
+int sfcvit_reduce_pending(void);
+int sfcvit_reduce_flush(void *stream);
+int sfcvit_reduce_discard(void);
+
 /* Column sums: out[n] = sum_m x[m, n] (bias gradients). x bf16 [M, ld]; out fp32 [N] (overwritten).
  * Two passes through `workspace` (sfcvit_colsum_workspace bytes, HOST query) instead of float atomics, so the
  * result is bit-reproducible from run to run. */

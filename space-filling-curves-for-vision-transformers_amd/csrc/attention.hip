@@ -345,7 +345,10 @@ extern "C" int sfcvit_attention_fwd(const sfcvit_attn_args *a, void *stream) {
 
 extern "C" int64_t sfcvit_attention_colsum_workspace(int B, int N, int H, int hd) {
     if (B <= 0 || N <= 0 || H <= 0 || hd <= 0) return 0;
-    const int64_t fused = int64_t(B) * 3 * H * hd * int64_t(sizeof(float)), generic = sfcvit_colsum_workspace(B * N, 3 * H * hd);
+    // one-pass backward: its [B][3D] partial rows, and behind them the partials of the pass over the Q third (two regions:
+    // with deferred reductions both are read at the flush)
+    const int64_t fused = int64_t(B) * 3 * H * hd * int64_t(sizeof(float)) + sfcvit_colsum_workspace(B * N, H * hd);
+    const int64_t generic = sfcvit_colsum_workspace(B * N, 3 * H * hd);
     return fused > generic ? fused : generic;
 }
 
@@ -368,10 +371,16 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
             const int dq_in_kernel = dq && dq[0] == 'k';
             if (int rc = attn_seq_bwd_fused(f, dq_in_kernel, s); rc >= 0) {
                 if (rc || !a->colsum_out) return rc;
-                if (int rc2 = launch_colsum_reduce(a->colsum_part, a->B, D3, a->colsum_out, a->colsum_bf16, stream)) return rc2;
-                if (dq_in_kernel) return SFCVIT_OK;
-                const int Dq = a->H * a->hd;                      // the Q third: columns 0 .. D-1 of dqkv, overwrites the zeros
-                return sfcvit_colsum(a->dqkv, a->B * a->N, Dq, D3, a->colsum_out, a->colsum_bf16, a->colsum_part, a->colsum_part_bytes, stream);
+                if (dq_in_kernel) return launch_colsum_reduce(a->colsum_part, a->B, D3, a->colsum_out, a->colsum_bf16, stream);
+                // K | V thirds from the kernel's partial rows, the Q third (columns 0 .. D-1 of dqkv) from its own pass; disjoint
+                // outputs and disjoint partial regions, so the two reductions may run in one deferred batch
+                const int Dq = a->H * a->hd;
+                char *outp = static_cast<char *>(a->colsum_out);
+                if (int rc2 = reduce_cols(a->colsum_part + Dq, a->B, D3, D3 - Dq, outp + size_t(Dq) * (a->colsum_bf16 ? 2 : 4), a->colsum_bf16, stream))
+                    return rc2;
+                const int64_t head = int64_t(a->B) * D3 * int64_t(sizeof(float));
+                return sfcvit_colsum(a->dqkv, a->B * a->N, Dq, D3, a->colsum_out, a->colsum_bf16, a->colsum_part + size_t(a->B) * D3,
+                                     a->colsum_part_bytes - head, stream);
             }
         }
     }

@@ -27,6 +27,11 @@ bool gemm_fused_actmask();    // ... with the activation bit mask written (act) 
 
 // rowwise.hip: out[n] = sum over `nparts` rows of part[nparts][N] in a fixed order; out fp32 or bf16.
 int launch_colsum_reduce(const float *part, int nparts, int N, void *out, int out_bf16, void *stream);
+// The general form: out[c] = sum_p part[p * ld + c], c < ncols.  Launched now -- or, between sfcvit_reduce_defer(1) and
+// sfcvit_reduce_defer(0), queued for ONE batched launch at sfcvit_reduce_flush (every such reduction of a backward pass
+// produces a parameter gradient nothing reads before the pass ends: 60 launches of 5 us per ViT-B step become one).
+int reduce_cols(const float *part, int nparts, int ld, int ncols, void *out, int out_bf16, void *stream);
+bool reduce_deferring();
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

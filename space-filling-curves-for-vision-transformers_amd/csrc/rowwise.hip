@@ -2,7 +2,11 @@
 // (bias gradients), GELU, soft-target cross-entropy, sum of squares and the fused
 // clip + AdamW step.  One 64-lane wave owns one row; every global access is a
 // 16-byte vector (8 bf16 or 4 fp32) and reductions are wave butterflies.
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 #include "common_host.h"
 #include "device_common.h"
 
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_cols_kernel(const uint16_t *__
     }
 }
 
-// Sum of per-block partials, shared by ln_bwd_reduce and colsum_reduce_kernel: a 1024-thread block owns 16 columns;
+// Sum of per-block partials, shared by ln_bwd_reduce and reduce_batched_kernel: a 1024-thread block owns 16 columns;
 // its 64 thread rows each add every 64th partial row (<= 8 independent loads in flight per thread for 512 partials,
 // where the 16-row form these kernels had serialised 32), then 4 thread rows add 16 sub-sums each and one adds those
 // 4.  Fixed summation order, no float atomics: bit-reproducible.  The value is returned in thread row 0.
@@ -427,12 +431,30 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(const uint16_t *__restr
     }
 }
 
-// out[c] = sum over row blocks in a fixed order (reduce_partials16 above).
-__global__ __launch_bounds__(RED_THREADS) void colsum_reduce_kernel(const float *__restrict__ part, int nparts, int N,
-                                                                   void *__restrict__ out, int as_bf16) {
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-    const float t = reduce_partials16(part, nparts, N, c, c < N);
-    if (threadIdx.x < 16 && c < N) store_grad(out, c, t, as_bf16);
+// Many such reductions in one launch (sfcvit_reduce_flush): a workgroup finds its item by the first-block table.
+constexpr int RED_BATCH = 96;
+struct ReduceItem {
+    const float *part;
+    void *out;
+    int nparts, ld, ncols, out_bf16;
+};
+struct ReduceBatch {                 // by value in the kernel arguments: 96 x 32 + 98 x 4 bytes < 4 KiB
+    ReduceItem it[RED_BATCH];
+    int first[RED_BATCH + 1];        // first workgroup of item i; first[n] = grid size
+    int n;
+};
+__global__ __launch_bounds__(RED_THREADS) void reduce_batched_kernel(const ReduceBatch b) {
+    int lo = 0, hi = b.n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (b.first[mid] <= int(blockIdx.x)) lo = mid; else hi = mid;
+    }
+    const float *part = b.it[lo].part;
+    void *out = b.it[lo].out;
+    const int nparts = b.it[lo].nparts, ld = b.it[lo].ld, ncols = b.it[lo].ncols, as_bf16 = b.it[lo].out_bf16;
+    const int c = (int(blockIdx.x) - b.first[lo]) * 16 + (threadIdx.x & 15);
+    const float t = reduce_partials16(part, nparts, ld, c, c < ncols);
+    if (threadIdx.x < 16 && c < ncols) store_grad(out, c, t, as_bf16);
 }
 
 // ---------------------------------------------------------------------------
@@ -811,6 +833,12 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     else LN_BWD(4);
 #undef LN_BWD
     if (int rc = check_launch("layernorm_bwd")) return rc;
+    if (reduce_deferring()) {            // queued for the batched launch at sfcvit_reduce_flush: partial rows are [3][D]
+        reduce_cols(part, nb, 3 * D, D, dgamma, grads_bf16, stream);
+        reduce_cols(part + D, nb, 3 * D, D, dbeta, grads_bf16, stream);
+        if (dcol) reduce_cols(part + 2 * D, nb, 3 * D, D, dcol, grads_bf16, stream);
+        return SFCVIT_OK;
+    }
     hipLaunchKernelGGL(ln_bwd_reduce, dim3((3 * D + 15) / 16), dim3(RED_THREADS), 0, s, part, dgamma, dbeta, dcol, nb, D, grads_bf16);
     return check_launch("layernorm_bwd_reduce");
 }
@@ -834,12 +862,68 @@ void colsum_plan(int M, int N, int &col_blocks, int &row_blocks, int &rpb) {
 }  // namespace
 
 namespace sfcvit {
+namespace {
+std::atomic<int> g_defer{0};
+std::mutex g_reduce_mutex;
+std::vector<ReduceItem> g_reduce_queue;
+}  // namespace
+
+bool reduce_deferring() { return g_defer.load(std::memory_order_relaxed) != 0; }
+
+int reduce_cols(const float *part, int nparts, int ld, int ncols, void *out, int out_bf16, void *stream) {
+    if (reduce_deferring()) {
+        std::lock_guard<std::mutex> lock(g_reduce_mutex);
+        g_reduce_queue.push_back(ReduceItem{part, out, nparts, ld, ncols, out_bf16});
+        return SFCVIT_OK;
+    }
+    ReduceBatch b;
+    b.it[0] = ReduceItem{part, out, nparts, ld, ncols, out_bf16};
+    b.first[0] = 0;
+    b.first[1] = (ncols + 15) / 16;
+    b.n = 1;
+    hipLaunchKernelGGL(reduce_batched_kernel, dim3(b.first[1]), dim3(RED_THREADS), 0, static_cast<hipStream_t>(stream), b);
+    return check_launch("column reduce");
+}
+
 int launch_colsum_reduce(const float *part, int nparts, int N, void *out, int out_bf16, void *stream) {
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 15) / 16), dim3(RED_THREADS), 0, static_cast<hipStream_t>(stream), part, nparts, N,
-                       out, out_bf16);
-    return check_launch("colsum reduce");
+    return reduce_cols(part, nparts, N, N, out, out_bf16, stream);
 }
 }  // namespace sfcvit
+
+extern "C" int sfcvit_reduce_defer(int on) { return g_defer.exchange(on ? 1 : 0); }
+
+extern "C" int sfcvit_reduce_pending(void) {
+    std::lock_guard<std::mutex> lock(g_reduce_mutex);
+    return int(g_reduce_queue.size());
+}
+
+extern "C" int sfcvit_reduce_discard(void) {
+    std::lock_guard<std::mutex> lock(g_reduce_mutex);
+    g_reduce_queue.clear();
+    return SFCVIT_OK;
+}
+
+extern "C" int sfcvit_reduce_flush(void *stream) {
+    std::vector<ReduceItem> items;
+    {
+        std::lock_guard<std::mutex> lock(g_reduce_mutex);
+        items.swap(g_reduce_queue);
+    }
+    for (size_t i0 = 0; i0 < items.size(); i0 += RED_BATCH) {
+        ReduceBatch b;
+        b.n = int(std::min(items.size() - i0, size_t(RED_BATCH)));
+        int blocks = 0;
+        for (int i = 0; i < b.n; i++) {
+            b.it[i] = items[i0 + i];
+            b.first[i] = blocks;
+            blocks += (b.it[i].ncols + 15) / 16;
+        }
+        b.first[b.n] = blocks;
+        hipLaunchKernelGGL(reduce_batched_kernel, dim3(blocks), dim3(RED_THREADS), 0, static_cast<hipStream_t>(stream), b);
+        if (int rc = check_launch("batched column reduce")) return rc;
+    }
+    return SFCVIT_OK;
+}
 
 extern "C" int64_t sfcvit_colsum_workspace(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
@@ -862,8 +946,7 @@ extern "C" int sfcvit_colsum(const void *x, int M, int N, int ld, void *out, int
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(THREADS), 0, s,
                        static_cast<const uint16_t *>(x), M, N, ld, rpb, part);
     if (int rc = check_launch("colsum")) return rc;
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 15) / 16), dim3(RED_THREADS), 0, s, part, row_blocks, N, out, out_bf16);
-    return check_launch("colsum reduce");
+    return reduce_cols(part, row_blocks, N, N, out, out_bf16, stream);
 }
 
 extern "C" int sfcvit_transpose(const void *src, int R, int C, int lds, void *dst, int ldd, void *stream) {

@@ -76,6 +76,10 @@ SIGNATURES = {
     "sfcvit_patch_embed_workspace": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "sfcvit_transpose": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sfcvit_transpose_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "sfcvit_reduce_defer": (c_int, [c_int]),
+    "sfcvit_reduce_pending": (c_int, []),
+    "sfcvit_reduce_flush": (c_int, [c_void_p]),
+    "sfcvit_reduce_discard": (c_int, []),
     "sfcvit_gemm_colsum_workspace": (c_int64, [c_int, c_int]),
     "sfcvit_last_gemm_kernel": (c_int, [ctypes.c_char_p, c_int]),
     "sfcvit_last_attn_kernel": (c_int, [ctypes.c_char_p, c_int]),

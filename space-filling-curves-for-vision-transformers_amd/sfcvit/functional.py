@@ -51,7 +51,9 @@ def _slot(p):
     if getattr(p, "_sfcvit_claimed", -1) == buf.epoch:
         return None                               # second use of a shared parameter in one backward: autograd must add
     p._sfcvit_claimed = buf.epoch
-    return buf.flat_grad[off:off + p.numel()].view(p.shape)
+    view = buf.flat_grad[off:off + p.numel()].view(p.shape)
+    view._sfcvit_deferrable = True          # ops._Deferring: a reduction that ends here may wait for the end of the backward pass
+    return view
 
 
 def _wgrad(dy2, x2, w=None):

@@ -168,6 +168,54 @@ def step_advance(state, beta1, beta2, seed_base):
     check(lib.sfcvit_step_advance(_p(state), beta1, beta2, seed_base & 0xFFFFFFFF, _stream()), "sfcvit_step_advance")
 
 
+# Deferred reductions (include/sfcvit.h: sfcvit_reduce_defer / _flush).  Bias, LayerNorm-parameter and similar gradients are
+# a main kernel + a 5-us fixed-order reduction over its partial rows; inside a backward pass nobody reads them before the pass
+# ends when they are written into gradient slots (functional._slot marks those views), so their reductions are queued and
+# run as ONE launch from an autograd end-of-pass callback (66 launches per ViT-B step become one).  A reducer that ships
+# gradients mid-pass calls flush_deferred(end=False) first.  SFCVIT_DEFER_REDUCE=0 switches it off (A/B, tests).
+import os as _os
+DEFER_REDUCES = _os.environ.get("SFCVIT_DEFER_REDUCE", "1") != "0"
+_defer = {"task": -1, "keep": []}
+
+
+def flush_deferred(end=True):
+    """Launch every queued reduction on the current stream (end=False: the backward pass goes on deferring)."""
+    if lib.sfcvit_reduce_pending():
+        check(lib.sfcvit_reduce_flush(_stream()), "sfcvit_reduce_flush")
+    _defer["keep"].clear()
+    if end:
+        _defer["task"] = -1
+
+
+class _Deferring:
+    """with _Deferring(outputs, workspaces): the C calls inside queue their final reductions iff every output is a
+    gradient slot and a backward pass is running; the workspaces then stay alive until the flush."""
+
+    def __init__(self, outs, keep):
+        self.on, self.keep = False, keep
+        if DEFER_REDUCES and outs and all(getattr(t, "_sfcvit_deferrable", False) for t in outs):
+            task = torch._C._current_graph_task_id()
+            if task >= 0:
+                if _defer["task"] != task:
+                    if lib.sfcvit_reduce_pending():      # a pass that died with reductions queued
+                        lib.sfcvit_reduce_discard()
+                    _defer["keep"].clear()
+                    _defer["task"] = task
+                    torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+                self.on = True
+
+    def __enter__(self):
+        if self.on:
+            lib.sfcvit_reduce_defer(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            lib.sfcvit_reduce_defer(0)
+            _defer["keep"].extend(self.keep)
+        return False
+
+
 def next_seed():
     """32-bit dropout seed drawn on the host from torch's default CPU generator: reproducible under
     torch.manual_seed, no device synchronisation (kernels receive it as a plain argument)."""
@@ -249,7 +297,8 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, bias=None, act=ACT_NONE, resid
         args.colsum_out, args.colsum_bf16 = cs.data_ptr(), int(cs.dtype == _BF16)
     key = "gemm %s" % {(False, False): "y=x.W^T (k-contig, k-contig)", (False, True): "dx=dy.W (k-contig, k-major)",
                        (True, True): "dW=dy^T.x (k-major, k-major)", (True, False): "(k-major, k-contig)"}[(a_kmajor, b_kmajor)]
-    check(_launch(key, 2.0 * M * N * K, lambda: lib.sfcvit_gemm(ctypes.byref(args), _stream())), "sfcvit_gemm")
+    with _Deferring([colsum] if cs is not None and colsum is not True else [], [ws] if cs is not None else []):
+        check(_launch(key, 2.0 * M * N * K, lambda: lib.sfcvit_gemm(ctypes.byref(args), _stream())), "sfcvit_gemm")
     if cs is not None:
         return (c, aux, cs) if want_aux else (c, cs)
     return (c, aux) if want_aux else c
@@ -298,8 +347,9 @@ def colsum(x, out=None):
         raise ValueError("colsum out: contiguous bf16 [N] expected")
     nbytes = lib.sfcvit_colsum_workspace(x.shape[0], x.shape[1])
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-    check(lib.sfcvit_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(out), int(out.dtype == _BF16), _p(ws), nbytes,
-                            _stream()), "sfcvit_colsum")
+    with _Deferring([out], [ws]):
+        check(lib.sfcvit_colsum(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(out), int(out.dtype == _BF16), _p(ws), nbytes,
+                                _stream()), "sfcvit_colsum")
     return out
 
 
@@ -340,11 +390,12 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0
     dcol = None
     if want_colsum:
         dcol = given[2] if given[2] is not None else torch.empty(D, device=x.device, dtype=gdt)
-    check(lib.sfcvit_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_add), _p(dx), _p(dx_drop),
-                                        drop_p, drop_seed, _seed_off() if drop_p > 0 else None, _p(dg), _p(db), _p(dcol),
-                                        int(gdt == _BF16), M, D, _p(ws),
-                                        _stream()),
-          "sfcvit_layernorm_bwd")
+    with _Deferring([dg, db] + ([dcol] if dcol is not None else []), [ws]):
+        check(lib.sfcvit_layernorm_bwd_drop(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx_add), _p(dx), _p(dx_drop),
+                                            drop_p, drop_seed, _seed_off() if drop_p > 0 else None, _p(dg), _p(db), _p(dcol),
+                                            int(gdt == _BF16), M, D, _p(ws),
+                                            _stream()),
+              "sfcvit_layernorm_bwd")
     out = (dx, dg, db) + ((dx_drop,) if drop_p > 0 else ()) + ((dcol,) if want_colsum else ())
     return out
 
@@ -418,8 +469,9 @@ def attention_bwd(qkv, out, lse, dout, n_heads, dropout_p=0.0, dropout_seed=0, c
         ws = torch.empty(nbytes, device=qkv.device, dtype=torch.uint8)
         a.colsum_part, a.colsum_part_bytes = ws.data_ptr(), nbytes
         a.colsum_out, a.colsum_bf16 = cs.data_ptr(), int(cs.dtype == _BF16)
-    check(_launch("attn_bwd", 10.0 * B * n_heads * N * N * hd,
-                  lambda: lib.sfcvit_attention_bwd(ctypes.byref(a), _stream())), "sfcvit_attention_bwd")
+    with _Deferring([colsum] if cs is not None and colsum is not True else [], [ws] if cs is not None else []):
+        check(_launch("attn_bwd", 10.0 * B * n_heads * N * N * hd,
+                      lambda: lib.sfcvit_attention_bwd(ctypes.byref(a), _stream())), "sfcvit_attention_bwd")
     return dqkv if cs is None else (dqkv, cs)
 
 

@@ -175,6 +175,9 @@ class GradReducer:
             self._handles.append((b, None))
             return
         _dbg(f"launch bucket {b} [{s}:{e}] (#{len(self._handles)} of this step)")
+        if self.opt.flat_grad.is_cuda:
+            from .. import ops
+            ops.flush_deferred(end=False)        # reductions queued for the end of the backward pass end in this bucket
         h = dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._handles.append((b, h))
         if self.backend == "nccl":

@@ -577,6 +577,55 @@ def test_weight_transposes_of_a_backward_pass_come_from_one_launch():
     assert l1 == l0 and torch.equal(m1, m0)
 
 
+def test_deferred_reductions_train_bit_identically_and_leave_nothing_queued():
+    """Bias / LayerNorm-parameter gradients written into gradient slots have their final reductions queued and launched once at
+    the end of the backward pass (ops._Deferring, sfcvit_reduce_flush).  Same kernels, same summation order: the run must
+    equal the one with SFCVIT_DEFER_REDUCE=0 bit for bit, gradients must be complete when backward() returns, and the
+    queue must be empty afterwards."""
+    from sfcvit import ops
+    from sfcvit._lib import lib
+    from sfcvit.models import VisionTransformer1D
+    from sfcvit.tokenizers import HilbertEmbedding1D
+    from sfcvit.training import FusedAdamW, mixup_soft_targets, train_step
+
+    def run(defer):
+        ops.DEFER_REDUCES = defer
+        flushes = {"n": 0, "items": 0}
+        flush = lib.sfcvit_reduce_flush
+
+        def counting(stream):
+            flushes["n"] += 1
+            flushes["items"] += lib.sfcvit_reduce_pending()
+            return flush(stream)
+        lib.sfcvit_reduce_flush = counting
+        try:
+            torch.manual_seed(11)
+            model = VisionTransformer1D(HilbertEmbedding1D(32, 16, 3, 256), depth=2, n_heads=4, mlp_dim=512, num_classes=16,
+                                        dropout_p=0.1, head_dropout_p=0.5).to("cuda", dtype=torch.bfloat16).train()
+            opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=5e-5, max_grad_norm=1.0)
+            g = torch.Generator(device="cuda").manual_seed(5)
+            x = torch.randn(8, 3, 32, 32, device="cuda", generator=g)
+            t = mixup_soft_targets(torch.randint(0, 16, (8,), device="cuda", generator=g), 16, lam=0.7)
+            losses = [float(train_step(model, x, t, opt)) for _ in range(3)]
+            assert lib.sfcvit_reduce_pending() == 0
+            # a bare backward: gradients are final when it returns (the engine's end-of-pass callback flushed the queue)
+            opt.zero_grad()
+            import sfcvit.functional as F
+            F.soft_target_cross_entropy(model(x), t).backward()
+            assert lib.sfcvit_reduce_pending() == 0
+            opt.adopt_all()
+            return losses, opt.master.clone(), opt.flat_grad.clone(), flushes
+        finally:
+            lib.sfcvit_reduce_flush = flush
+            ops.DEFER_REDUCES = True
+    l1, m1, g1, f1 = run(True)
+    l0, m0, g0, f0 = run(False)
+    assert f0["n"] == 0
+    # the first step has no slots yet (the flat buffers are built by its optimizer step): three later backward passes defer
+    assert f1["n"] == 3 and f1["items"] >= 3 * 10, f1
+    assert l1 == l0 and torch.equal(m1, m0) and torch.equal(g1, g0)
+
+
 def test_shared_parameter_gradient_accumulates_once_per_use():
     """A weight used twice in one backward: the first use may claim the in-place gradient slot, the second must be
     ADDED by autograd (functional._slot hands the slot out once per zero_grad epoch)."""
