@@ -260,7 +260,7 @@ def main():
         loss = step()
     timing = rank == 0 and not args.no_kernel_timing and not args.graph
     if timing:
-        ops.TIMER = ops.KernelTimer(None if args.time_all_kernels else ("gemm ", "attn", "pe_"))
+        ops.TIMER = ops.KernelTimer(None if args.time_all_kernels else ("gemm ", "attn", "pe_", "tokens_gather"))
     if reducer is not None:
         reducer.reset_stats()
     sync()
@@ -362,6 +362,9 @@ def main():
                 detail["patch_embed_fwd"] = frac_entry(kern["pe_fwd_kernel"], bytes_per_launch=pe_in + bh * D * 2 + D * 3 * patch * 2)
             if "pe_bwd_kernel" in kern:
                 detail["patch_embed_bwd"] = frac_entry(kern["pe_bwd_kernel"], bytes_per_launch=pe_in + bh * D * 2 + D * 3 * patch * 4)
+            if "tokens_gather" in kern:     # two-stage patch embed: the gather alone (HBM-bound: image in, bf16 tokens out); its
+                # projection and weight gradient are ordinary launches of the GEMM families above
+                detail["tokens_gather"] = frac_entry(kern["tokens_gather"], bound_flops=False, bytes_per_launch=pe_in + bh * 3 * patch * 2)
             detail["step"] = {"tflops": out["step_tflops_per_gpu"], "mfma_frac": out["step_mfma_frac"]}
             out["roofline_detail"] = detail
             out["kernel_timing"] = (f"HIP events around every launch of the GEMMs / attention / patch embed in {tsteps} of the "

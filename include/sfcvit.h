@@ -111,6 +111,15 @@ int sfcvit_tile_descriptors(const int32_t *pix, int N, int P, int img_w, int32_t
 int64_t sfcvit_patch_embed_workspace(int B, int C, int N, int P, int D, int bwd);
 
 int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *stream);
+/* The gather alone: tokens[b * N + n][kk * C + c] = bf16(x[b, c, pix[n][kk]]) -- the reference's
+ * `x_flat[:, :, perm].reshape(B, N, P * C)` (src/tokenizers/_1D/hilbert_embedding1D.py:36-41) as one pass: the image is read
+ * once (every 16 x 16 tile of a Hilbert / Z token by one workgroup), rows are written whole.  tokens is [B * N, ld] bf16 with
+ * ld >= P * C, ld % 8 == 0 (columns P * C .. ld - 1 are zeroed).  order (device, [N], or NULL) = the tokens sorted by their
+ * lowest pixel offset: workgroups then take horizontally adjacent 16 x 16 tiles in pairs, whose 64-byte rows share
+ * 128-byte lines (a performance hint only; any permutation of 0 .. N - 1 gives the same tokens).  Two-stage patch embed = this + sfcvit_gemm (round 3: at
+ * ViT-B the persistent GEMMs run the projection and its weight gradient 2-3x faster than the fused gather kernels). */
+int sfcvit_tokens_gather(const void *x, int x_is_bf16, const int32_t *pix, const int32_t *order, int B, int C, int HW, int N, int P,
+                         void *tokens, int ld, void *stream);
 /* dW = sum_{b,t} dY[b,t,:]^T tokens[b,t,:] with the tokens re-gathered from x
  * (nothing but x is saved for backward); the image receives no gradient. */
 int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *stream);

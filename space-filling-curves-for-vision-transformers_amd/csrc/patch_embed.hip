@@ -257,6 +257,117 @@ int64_t pe2_bwd_workspace(int B, int C, int N, int D);
 
 using namespace sfcvit;
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The gather alone (sfcvit_tokens_gather): one workgroup per (token n, group of IMG images).  The token's P pixel offsets
+// are read once; per image every thread loads its pixels' C channel values (4-byte / 2-byte loads that between them
+// use every byte of the token's image lines), rounds to bf16 into an LDS row in the reference's feature order
+// kk * C + c, and the row leaves as 16-byte stores.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace sfcvit {
+namespace {
+constexpr int GT = 256, GIMG = 8;
+
+template <bool XBF16>
+__global__ __launch_bounds__(GT) void tokens_gather_kernel(const void *__restrict__ x, const int32_t *__restrict__ pix,
+                                                           uint16_t *__restrict__ tokens, int B, int C, int HW, int N, int P, int ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem_g[];
+    uint16_t *row = reinterpret_cast<uint16_t *>(smem_g);                 // [ld]
+    const int n = blockIdx.x, b0 = blockIdx.y * GIMG, tid = threadIdx.x, K = P * C;
+    for (int i = K + tid; i < ld; i += GT) row[i] = 0;                     // padding columns
+    for (int b = b0; b < min(B, b0 + GIMG); b++) {
+        const size_t img = size_t(b) * C * HW;
+        for (int kk = tid; kk < P; kk += GT) {
+            const int off = pix[size_t(n) * P + kk];
+            for (int c = 0; c < C; c++) {
+                const size_t src = img + size_t(c) * HW + off;
+                row[kk * C + c] = XBF16 ? static_cast<const uint16_t *>(x)[src] : f2bf(static_cast<const float *>(x)[src]);
+            }
+        }
+        __syncthreads();
+        uint16_t *dst = tokens + (size_t(b) * N + n) * ld;
+        for (int v = tid; v < ld / 8; v += GT) *reinterpret_cast<u32x4 *>(dst + v * 8) = *reinterpret_cast<const u32x4 *>(row + v * 8);
+        __syncthreads();
+    }
+}
+
+// P <= 256 (every reference tokenizer: 16, 64 or 256 pixels per token), C <= 4: one pixel per thread, the loads of all GIMG
+// images in flight at once, one barrier per workgroup -- and TWO tokens per workgroup, taken from `order`: a 16 x 16 tile's
+// rows are 64 bytes of fp32, half a 128-byte line whose other half belongs to the tile next to it; with one token per
+// workgroup every line of the image was fetched twice (62 us at ViT-B / 256 images: 154 MB of image read as 308).  The
+// caller orders the tokens by their lowest pixel offset, which puts horizontal neighbours side by side.
+template <bool XBF16, int CMAX>
+__global__ __launch_bounds__(2 * GT) void tokens_gather_p256_kernel(const void *__restrict__ x, const int32_t *__restrict__ pix,
+                                                                    const int32_t *__restrict__ order, uint16_t *__restrict__ tokens,
+                                                                    int B, int C, int HW, int N, int P, int ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem_g[];
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & (GT - 1);
+    const int slot = 2 * blockIdx.x + half;
+    uint16_t *rows = reinterpret_cast<uint16_t *>(smem_g) + size_t(half) * GIMG * ld;   // [2][GIMG][ld]
+    const int b0 = blockIdx.y * GIMG, K = P * C;
+    const int nb = min(GIMG, B - b0);
+    const bool live = slot < N;
+    const int n = live ? (order ? order[slot] : slot) : 0;
+    uint16_t v[GIMG][CMAX];
+    if (live && tid < P) {
+        const int off = pix[size_t(n) * P + tid];
+#pragma unroll
+        for (int i = 0; i < GIMG; i++) {
+            if (i < nb) {
+                const size_t img = size_t(b0 + i) * C * HW + off;
+#pragma unroll
+                for (int c = 0; c < CMAX; c++)
+                    if (c < C) v[i][c] = XBF16 ? static_cast<const uint16_t *>(x)[img + size_t(c) * HW] : f2bf(static_cast<const float *>(x)[img + size_t(c) * HW]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GIMG; i++)
+            if (i < nb)
+#pragma unroll
+                for (int c = 0; c < CMAX; c++)
+                    if (c < C) rows[i * ld + tid * C + c] = v[i][c];
+    }
+    if (live)
+        for (int i = K + tid; i < ld; i += GT)
+            for (int r = 0; r < nb; r++) rows[r * ld + i] = 0;
+    __syncthreads();
+    if (!live) return;
+    const int vpr = ld / 8;
+    for (int j = tid; j < nb * vpr; j += GT) {
+        const int r = j / vpr, vv = j - r * vpr;
+        *reinterpret_cast<u32x4 *>(tokens + (size_t(b0 + r) * N + n) * ld + vv * 8) = *reinterpret_cast<const u32x4 *>(rows + r * ld + vv * 8);
+    }
+}
+
+}  // namespace
+}  // namespace sfcvit
+
+extern "C" int sfcvit_tokens_gather(const void *x, int x_is_bf16, const int32_t *pix, const int32_t *order, int B, int C, int HW, int N,
+                                    int P, void *tokens, int ld, void *stream) {
+    using namespace sfcvit;
+    if (!x || !pix || !tokens) return fail(SFCVIT_EINVAL, "tokens_gather: null pointer");
+    if (B <= 0 || C <= 0 || HW <= 0 || N <= 0 || P <= 0 || int64_t(N) * P != HW)
+        return fail(SFCVIT_EINVAL, "tokens_gather: B=%d C=%d HW=%d N=%d P=%d (N * P must equal H * W)", B, C, HW, N, P);
+    if (ld < P * C || ld % 8 || ld > 32768) return fail(SFCVIT_EINVAL, "tokens_gather: ld=%d (>= P * C = %d, multiple of 8, <= 32768)", ld, P * C);
+    if (!aligned16(tokens)) return fail(SFCVIT_EINVAL, "tokens_gather: tokens must be 16-byte aligned");
+    const dim3 grid(N, (B + GIMG - 1) / GIMG);
+    if (grid.y > 65535) return fail(SFCVIT_EINVAL, "tokens_gather: batch %d too large", B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (P <= GT && C <= 4 && size_t(2) * GIMG * ld * 2 <= 64 * 1024) {
+        const dim3 grid2((N + 1) / 2, grid.y);
+        const size_t lds = size_t(2) * GIMG * ld * 2;
+        if (x_is_bf16)
+            hipLaunchKernelGGL((tokens_gather_p256_kernel<true, 4>), grid2, dim3(2 * GT), lds, s, x, pix, order, static_cast<uint16_t *>(tokens), B, C, HW, N, P, ld);
+        else
+            hipLaunchKernelGGL((tokens_gather_p256_kernel<false, 4>), grid2, dim3(2 * GT), lds, s, x, pix, order, static_cast<uint16_t *>(tokens), B, C, HW, N, P, ld);
+        return check_launch("tokens_gather");
+    }
+    if (x_is_bf16)
+        hipLaunchKernelGGL(tokens_gather_kernel<true>, grid, dim3(GT), size_t(ld) * 2, s, x, pix, static_cast<uint16_t *>(tokens), B, C, HW, N, P, ld);
+    else
+        hipLaunchKernelGGL(tokens_gather_kernel<false>, grid, dim3(GT), size_t(ld) * 2, s, x, pix, static_cast<uint16_t *>(tokens), B, C, HW, N, P, ld);
+    return check_launch("tokens_gather");
+}
+
 extern "C" int64_t sfcvit_patch_embed_workspace(int B, int C, int N, int P, int D, int bwd) {
     if (B <= 0 || C <= 0 || N <= 0 || P <= 0 || D <= 0) return 0;
     const int64_t K = (int64_t(C) * P + 7) / 8 * 8;

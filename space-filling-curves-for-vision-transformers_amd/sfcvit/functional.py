@@ -113,6 +113,31 @@ def _bgrad(dy2, b=None):
 
 
 # ----------------------------------------------------------------------------
+PE_TWO_STAGE = _os.environ.get("SFCVIT_PE_FUSED", "0") != "1"   # "1": the fused gather-GEMM kernels (rounds 1-2) instead of gather + GEMM
+
+
+class _PatchEmbed2(Function):
+    """Gather, then project (round 3).  The fused kernels of rounds 1-2 make the gather the A loader of their own GEMM and run
+    it at 280 TFLOP/s (192 us forward, 185 + 30 us backward at ViT-B / 256 images, the image read 2-3 times); materialising the
+    token matrix once (154 MB of fp32 image in, 77 MB of bf16 tokens out) lets the projection and its weight gradient run on
+    the persistent GEMMs at 950-1 150 TFLOP/s -- what the reference does (hilbert_embedding1D.py:36-43), minus its reshape copy."""
+
+    @staticmethod
+    def forward(ctx, x, pix, w, b):
+        B, (N, P) = x.shape[0], pix.shape
+        tokens = ops.gather_tokens(_c(x), pix)
+        ctx.save_for_backward(tokens, w)
+        ctx.small = (b,)
+        return ops.gemm(tokens, w, bias=b).view(B, N, w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        tokens, w = ctx.saved_tensors
+        dy2 = _c(dy).view(-1, dy.shape[-1])
+        b = ctx.small[0]
+        return None, None, _wgrad(dy2, tokens, w), (_bgrad(dy2, b) if b is not None else None)
+
+
 class _PatchEmbed(Function):
     @staticmethod
     def forward(ctx, x, pix, w, b, desc):
@@ -145,12 +170,20 @@ def _traced():
     return torch.compiler.is_compiling()
 
 
+def pe_two_stage(x, pix):
+    """Gather + GEMM (default) or the fused kernels?  The GEMM wants 16-byte rows: P * C a multiple of 8."""
+    return PE_TWO_STAGE and (pix.shape[1] * x.shape[1]) % 8 == 0
+
+
 def patch_embed(x, pix, weight, bias, desc=None):
-    """Fused curve gather + patchify + projection: x [B,C,H,W] (fp32 or bf16) -> [B,N,D] bf16.
-    desc = ops.TileDesc of the pixel table (tokens are 16 x 16 tiles / 256-pixel strips) or None."""
+    """Curve gather + patchify + projection: x [B,C,H,W] (fp32 or bf16) -> [B,N,D] bf16.
+    desc = ops.TileDesc of the pixel table (tokens are 16 x 16 tiles / 256-pixel strips) or None (only the fused kernels
+    of SFCVIT_PE_FUSED=1 use it)."""
     if _traced():
         from . import library
         return library.patch_embed(x, pix, _bf(weight), _bf(bias), desc)
+    if pe_two_stage(x, pix):
+        return _PatchEmbed2.apply(x, pix, _bf(weight), _bf(bias))
     return _PatchEmbed.apply(x, pix, _bf(weight), _bf(bias), desc)
 
 

@@ -124,6 +124,50 @@ def _pe_backward(ctx, dy, _dxs):
 patch_embed_op.register_autograd(_pe_backward, setup_context=_pe_setup)
 
 
+# the two-stage form (functional._PatchEmbed2: gather, then the projection on the GEMM kernels): y, tokens
+@torch.library.custom_op("sfcvit::patch_embed2", mutates_args=())
+def patch_embed2_op(x: Tensor, pix: Tensor, w: Tensor, b: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    ctx = _Ctx()
+    y = F._PatchEmbed2.forward(ctx, x, pix, w, b)
+    return y.contiguous(), ctx.saved_tensors[0]
+
+
+@patch_embed2_op.register_fake
+def _(x, pix, w, b):
+    B, (N, P) = x.shape[0], pix.shape
+    return x.new_empty((B, N, w.shape[0]), dtype=_BF16), x.new_empty((B * N, (P * x.shape[1] + 7) // 8 * 8), dtype=_BF16)
+
+
+@torch.library.custom_op("sfcvit::patch_embed2_bwd", mutates_args=())
+def patch_embed2_bwd_op(dy: Tensor, tokens: Tensor, w: Tensor, has_bias: bool) -> Tuple[Tensor, Tensor]:
+    ctx = _Ctx()
+    ctx.saved_tensors, ctx.small = (tokens, w), (w.new_empty(0) if has_bias else None,)
+    with _no_slots():
+        _, _, dw, db = F._PatchEmbed2.backward(ctx, dy)
+    return dw, (db if db is not None else _e(dy))
+
+
+@patch_embed2_bwd_op.register_fake
+def _(dy, tokens, w, has_bias):
+    return dy.new_empty(w.shape), dy.new_empty(w.shape[0] if has_bias else 0)
+
+
+def _pe2_setup(ctx, inputs, output):
+    x, pix, w, b = inputs
+    ctx.save_for_backward(output[1], w)
+    ctx.has_bias = b is not None
+    ctx.set_materialize_grads(False)
+
+
+def _pe2_backward(ctx, dy, _dtokens):
+    tokens, w = ctx.saved_tensors
+    dw, db = torch.ops.sfcvit.patch_embed2_bwd(dy.contiguous(), tokens, w, ctx.has_bias)
+    return None, None, dw, (db if ctx.has_bias else None)
+
+
+patch_embed2_op.register_autograd(_pe2_backward, setup_context=_pe2_setup)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # mixer_block
 # ----------------------------------------------------------------------------------------------------------------------
@@ -352,6 +396,8 @@ soft_ce_op.register_autograd(_ce_backward, setup_context=_ce_setup)
 # entry points used by sfcvit.functional when torch.compiler.is_compiling()
 # ----------------------------------------------------------------------------------------------------------------------
 def patch_embed(x, pix, weight, bias, desc):
+    if F.pe_two_stage(x, pix):
+        return torch.ops.sfcvit.patch_embed2(x.contiguous(), pix, weight, bias)[0]
     meta = [desc.mode, desc.ncls, *desc.cnt] if desc is not None else []
     return torch.ops.sfcvit.patch_embed(x, pix, weight, bias, desc.dev if desc is not None else None, meta)[0]
 

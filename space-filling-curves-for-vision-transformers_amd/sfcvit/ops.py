@@ -523,6 +523,27 @@ def _pe_args(x, pix, n_tokens, P, D):
     return a
 
 
+_GATHER_ORDER = {}
+
+
+def gather_tokens(x, pix):
+    """x [B,C,H,W] fp32/bf16, pix [N,P] int32 (device) -> tokens [B*N, P*C (rounded up to 8)] bf16 in the reference's
+    feature order kk * C + c (sfcvit_tokens_gather): the A operand of the projection GEMM and of its weight gradient."""
+    N, P = pix.shape
+    a = _pe_args(x, pix, N, P, 8)
+    ld = (P * a.C + 7) // 8 * 8
+    tokens = torch.empty((a.B * N, ld), device=x.device, dtype=_BF16)
+    key = (pix.data_ptr(), pix._version, N, P)
+    order = _GATHER_ORDER.get(key)
+    if order is None:                              # once per pixel table: tokens by lowest pixel offset (neighbouring tiles pair up)
+        if len(_GATHER_ORDER) > 64:
+            _GATHER_ORDER.clear()
+        order = _GATHER_ORDER[key] = pix.min(dim=1).values.argsort().to(torch.int32).contiguous()
+    check(_launch("tokens_gather", 0.0, lambda: lib.sfcvit_tokens_gather(_p(x), a.x_is_bf16, _p(pix), _p(order), a.B, a.C, a.HW, N, P,
+                                                                       _p(tokens), ld, _stream())), "sfcvit_tokens_gather")
+    return tokens
+
+
 def patch_embed_fwd(x, pix, w, bias, desc=None):
     """x [B,C,H,W] fp32/bf16, pix [N,P] int32 (device), w [D, P*C] bf16 -> [B, N, D] bf16.
     desc: TileDesc (tile_descriptor) or None; with it the tiled kernel runs when P = 256 and D % 256 == 0."""

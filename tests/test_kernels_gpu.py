@@ -827,3 +827,24 @@ def test_transpose_batched_matches_torch(ops):
     ops.transpose_batched(src, dst, tiles, len(rows))
     for m, o in zip(mats, offs):
         assert torch.equal(dst[o:o + m.numel()].view(m.shape[1], m.shape[0]), m.t().contiguous())
+
+
+@pytest.mark.parametrize("curve,img,P,C,B,xdt", [("hilbert", 224, 256, 3, 3, torch.float32), ("z", 384, 256, 3, 2, torch.float32),
+                                                 ("raster", 224, 256, 3, 9, torch.bfloat16), ("hilbert", 32, 16, 3, 37, torch.float32),
+                                                 ("hilbert", 32, 64, 1, 5, torch.float32), ("z", 32, 4, 3, 2, torch.float32)])
+def test_tokens_gather_is_the_reference_gather(ops, curve, img, P, C, B, xdt):
+    """sfcvit_tokens_gather against torch indexing with the same pixel table (hilbert_embedding1D.py:36-41: x_flat[:, :, perm]
+    -> [B, N, P * C], feature = k * C + c): bit-exact (one bf16 rounding of the same pixels); rows padded to 8 columns are
+    zero-filled (P * C = 12 here)."""
+    from sfcvit.tokenizers.embeddings import _pixel_table
+    from sfcvit.curves import curve_table, hilbert_curve, z_curve
+    g = torch.Generator(device="cuda").manual_seed(3)
+    flat = np.arange(img * img, dtype=np.int32) if curve == "raster" else curve_table({"hilbert": hilbert_curve, "z": z_curve}[curve], img)
+    pix = torch.from_numpy(_pixel_table(flat, img, 1, P)).cuda()
+    x = torch.randn(B, C, img, img, device="cuda", generator=g).to(xdt)
+    tokens = ops.gather_tokens(x, pix)
+    N, K = pix.shape[0], P * C
+    ref = x.to(torch.bfloat16).reshape(B, C, img * img)[:, :, pix.long()].permute(0, 2, 3, 1).reshape(B * N, K)
+    assert tokens.shape == (B * N, (K + 7) // 8 * 8)
+    assert torch.equal(tokens[:, :K], ref)
+    assert not tokens[:, K:].any()

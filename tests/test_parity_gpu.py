@@ -577,6 +577,31 @@ def test_weight_transposes_of_a_backward_pass_come_from_one_launch():
     assert l1 == l0 and torch.equal(m1, m0)
 
 
+def test_two_stage_and_fused_patch_embed_agree():
+    """Default: sfcvit_tokens_gather + the projection on the GEMM kernels (functional._PatchEmbed2); SFCVIT_PE_FUSED=1: the fused
+    gather-GEMM kernels of rounds 1-2.  Same tokens (one bf16 rounding of the same pixels), same products, another summation
+    order: embeddings within bf16 rounding, weight gradients within the split-K tolerance."""
+    import sfcvit.functional as F
+    from sfcvit.tokenizers import HilbertEmbedding1D
+    torch.manual_seed(4)
+    tok = HilbertEmbedding1D(224, 256, 3, 768).to("cuda", dtype=torch.bfloat16)
+    x = torch.randn(6, 3, 224, 224, device="cuda")
+    gy = torch.randn(6, 196, 768, device="cuda").to(torch.bfloat16)
+    res = {}
+    for two in (True, False):
+        F.PE_TWO_STAGE = two
+        try:
+            tok.zero_grad()
+            y = tok(x)
+            y.backward(gy)
+            res[two] = (y.detach().float(), tok.proj.weight.grad.float().clone(), tok.proj.bias.grad.float().clone())
+        finally:
+            F.PE_TWO_STAGE = True
+    for a, b, tol in zip(res[True], res[False], (1 / 128, 1 / 64, 1 / 64)):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
+    assert float(torch.nn.functional.cosine_similarity(res[True][1].flatten(), res[False][1].flatten(), dim=0)) > 0.9999
+
+
 def test_deferred_reductions_train_bit_identically_and_leave_nothing_queued():
     """Bias / LayerNorm-parameter gradients written into gradient slots have their final reductions queued and launched once at
     the end of the backward pass (ops._Deferring, sfcvit_reduce_flush).  Same kernels, same summation order: the run must

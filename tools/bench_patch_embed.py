@@ -27,6 +27,10 @@ b = torch.zeros(D, device="cuda").bfloat16()
 dy = torch.randn(B, N, D, device="cuda", generator=g).bfloat16()
 
 
+tok = ops.gather_tokens(x, pix)
+dy2 = dy.view(B * N, D)
+
+
 def timeit(fn, reps=10):
     for _ in range(2):
         fn()
@@ -45,6 +49,11 @@ cases = {
     "fwd tiled (bf16 image)": lambda: ops.patch_embed_fwd(xb, pix, w, b, desc),
     "fwd generic (bf16 image)": lambda: ops.patch_embed_fwd(xb, pix, w, b, None),
     "fp32 -> bf16 cast of the image": lambda: x.bfloat16(),
+    "gather (fp32 image -> bf16 tokens)": lambda: ops.gather_tokens(x, pix),
+    "gather (bf16 image)": lambda: ops.gather_tokens(xb, pix),
+    "projection GEMM on the tokens": lambda: ops.gemm(tok, w, bias=b),
+    "two-stage fwd (gather + GEMM)": lambda: ops.gemm(ops.gather_tokens(x, pix), w, bias=b),
+    "two-stage bwd (dW GEMM + dbias)": lambda: (ops.gemm(dy2, tok, a_kmajor=True, b_kmajor=True), ops.colsum(dy2)),
     "bwd tiled (fp32 image)": lambda: ops.patch_embed_bwd(x, pix, dy, D, True, desc),
     "bwd generic (bf16 image)": lambda: ops.patch_embed_bwd(xb, pix, dy, D, True, None),
 }
