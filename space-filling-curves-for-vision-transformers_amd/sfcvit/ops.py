@@ -176,6 +176,8 @@ def step_advance(state, beta1, beta2, seed_base):
 import os as _os
 DEFER_REDUCES = _os.environ.get("SFCVIT_DEFER_REDUCE", "1") != "0"
 _defer = {"task": -1, "keep": []}
+# autograd's id of the running backward pass (-1 outside one); a torch without it simply never defers / batches
+graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)
 
 
 def flush_deferred(end=True):
@@ -194,7 +196,7 @@ class _Deferring:
     def __init__(self, outs, keep):
         self.on, self.keep = False, keep
         if DEFER_REDUCES and outs and all(getattr(t, "_sfcvit_deferrable", False) for t in outs):
-            task = torch._C._current_graph_task_id()
+            task = graph_task_id()
             if task >= 0:
                 if _defer["task"] != task:
                     if lib.sfcvit_reduce_pending():      # a pass that died with reductions queued
@@ -533,7 +535,7 @@ def gather_tokens(x, pix):
     a = _pe_args(x, pix, N, P, 8)
     ld = (P * a.C + 7) // 8 * 8
     tokens = torch.empty((a.B * N, ld), device=x.device, dtype=_BF16)
-    key = (pix.data_ptr(), pix._version, N, P)
+    key = (pix.device.index, pix.data_ptr(), pix._version, N, P)
     order = _GATHER_ORDER.get(key)
     if order is None:                              # once per pixel table: tokens by lowest pixel offset (neighbouring tiles pair up)
         if len(_GATHER_ORDER) > 64:

@@ -48,6 +48,7 @@ class FlatGradBuffer:
             self._check(p)
             if p.dtype != dtype:
                 raise TypeError("all parameters must share one dtype")
+        self._wt = None                              # (a rebuilt layout invalidates the transposed-weight table)
         self.offsets, off = [], 0
         for p in self.active:
             self.offsets.append(off)
@@ -76,7 +77,7 @@ class FlatGradBuffer:
         valid for that backward pass only -- keyed by autograd's graph-task id, inside which the weights cannot change --
         so there is no invalidation rule to get wrong.  Outside a backward pass, for parameters outside the flat buffer,
         or with SFCVIT_WT_CACHE=0: None (the caller transposes by itself)."""
-        task = torch._C._current_graph_task_id()
+        task = ops.graph_task_id()
         if task < 0 or self.flat_param is None or not self.flat_param.is_cuda or not _WT_CACHE:
             return None
         if self._wt is None:
