@@ -1040,7 +1040,10 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     if (a.bias && a.N > BIAS_MAX_N) return -1;               // the bias vector lives in LDS
     const int cus = device_cus() / 8 * 8;
     if (cus < 8) return -1;
-    // Tile height: the one whose last round of tiles wastes least (cost = rounds x rows per tile).
+    // Tile height: the one whose rounds of tiles cost least.  A tile's time is not proportional to its rows: the stamped
+    // k-tile (profiles/r3/gemm8p_ktile_trace.txt) takes 2 663 clocks at 256 rows and 2 487 at 224 (0.934, not 0.875) -- the
+    // per-section hand-off does not shrink with the tile; 192 rows extrapolated.  With these weights N = 3 072 at M = 50 176
+    // takes 256-row tiles (10 rounds x 1 000 < 11 x 934; measured 234 vs 238 us and 219 vs 226 us), N = 768 stays at 224.
     const int nt = a.N / 256;
     long best = -1;
     int ni = 0;
@@ -1051,7 +1054,7 @@ int gemm8p_dispatch(const sfcvit_gemm_args &a, int splits, hipStream_t s) {
     for (int cand : {8, 7, 6}) {
         if (a.M < 32 * cand || (a.M % (32 * cand) && aliased)) continue;
         const long tiles = long((a.M + 32 * cand - 1) / (32 * cand)) * nt;
-        const long cost = ((tiles + cus - 1) / cus) * cand;
+        const long cost = ((tiles + cus - 1) / cus) * (cand == 8 ? 1000 : cand == 7 ? 934 : 870);
         if (best < 0 || cost < best) { best = cost; ni = cand; }
     }
     if (!ni) return -1;
