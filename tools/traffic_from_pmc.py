@@ -51,7 +51,7 @@ def main():
                        "are included in FETCH_SIZE.",
            "build": sys.argv[3] if len(sys.argv) > 3 else "", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
-        if not ("gemm" in k or "attn" in k or "ln_" in k or "pe_" in k or "pe2_" in k or "adamw" in k or "colsum" in k or "transpose" in k):
+        if not ("gemm" in k or "attn" in k or "ln_" in k or "pe_" in k or "pe2_" in k or "adamw" in k or "colsum" in k or "transpose" in k or "gather" in k or "reduce" in k or "gelu" in k):
             continue
         f, nf = fetch.get(k, (0.0, 0))
         w, _ = write.get(k, (0.0, 0))
