@@ -117,4 +117,7 @@ FULL_CASES = {
 TRAIN_CASES = {
     "hilbert32_1d": ("hilbert32_1d", 3, 1e-3, 5e-2),
     "raster32_2d": ("raster32_2d", 3, 1e-3, 5e-5),
+    # a rate at which the 4-image batch does not overshoot (the two cases above do: 2.55 -> 1.00 -> 1.03): the trajectories
+    # of implementations stay together, so the per-step tolerances need no widening
+    "hilbert32_1d_lr1e4": ("hilbert32_1d", 4, 1e-4, 5e-2),
 }

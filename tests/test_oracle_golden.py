@@ -237,7 +237,7 @@ def oracle_train_run(name):
     return losses, norms, sd
 
 
-@pytest.mark.parametrize("name", ["hilbert32_1d", "raster32_2d"])
+@pytest.mark.parametrize("name", ["hilbert32_1d", "raster32_2d", "hilbert32_1d_lr1e4"])
 def test_train_steps_against_reference_fixture(name, golden_dir):
     """Three optimisation steps (zero_grad, forward, soft-target CE, backward, clip 1.0, AdamW) of the oracle against
     the same steps taken by the reference model with torch.optim.AdamW: per-step loss and the weights afterwards."""

@@ -485,7 +485,12 @@ def test_train_steps_match_oracle_and_reference(name, golden_dir):
     clip + fp32-master AdamW -- against oracle.vit_oracle.train_step and the fixture from the reference model with
     torch.optim.AdamW.  Tolerances (bf16 forward/backward vs fp32): per-step loss 1e-2 relative (+5e-3 per further step); pre-clip gradient
     norm 3 % (+1 % per further step); the UPDATE (master weight after 3 steps minus initial value) of every parameter with a non-negligible
-    gradient: cosine >= 0.9 with the oracle's update and every element within 2 * lr * steps (Adam's maximum drift)."""
+    gradient: cosine >= 0.9 with the oracle's update and every element within 2 * lr * steps (Adam's maximum drift).
+
+    TRAIN_CASES also holds a non-overshooting rate (hilbert32_1d_lr1e4: 2.56 -> 2.03 -> 1.64 -> 1.35 in the reference); it pins
+    the fp32 oracle (test_oracle_golden) but is no tighter a check HERE: Adam moves every element by ~lr = 1e-4 per step, less
+    than half a bf16 ulp of most weights, so the bf16 working copy the forward reads follows the fp32 master with a lag (measured:
+    2.553 -> 2.338 -> 1.799 -> 1.334) -- the behaviour of bf16 weights with an fp32 master, not a property of the kernels."""
     from oracle.cases import TRAIN_CASES
     from test_oracle_golden import oracle_train_run
     with open(os.path.join(golden_dir, f"train_{name}.json")) as f:
