@@ -487,10 +487,8 @@ def test_train_steps_match_oracle_and_reference(name, golden_dir):
     norm 3 % (+1 % per further step); the UPDATE (master weight after 3 steps minus initial value) of every parameter with a non-negligible
     gradient: cosine >= 0.9 with the oracle's update and every element within 2 * lr * steps (Adam's maximum drift).
 
-    TRAIN_CASES also holds a non-overshooting rate (hilbert32_1d_lr1e4: 2.56 -> 2.03 -> 1.64 -> 1.35 in the reference); it pins
-    the fp32 oracle (test_oracle_golden) but is no tighter a check HERE: Adam moves every element by ~lr = 1e-4 per step, less
-    than half a bf16 ulp of most weights, so the bf16 working copy the forward reads follows the fp32 master with a lag (measured:
-    2.553 -> 2.338 -> 1.799 -> 1.334) -- the behaviour of bf16 weights with an fp32 master, not a property of the kernels."""
+    TRAIN_CASES also holds a non-overshooting rate (hilbert32_1d_lr1e4): see
+    test_train_steps_at_a_small_rate_follow_the_bf16_working_weight_oracle."""
     from oracle.cases import TRAIN_CASES
     from test_oracle_golden import oracle_train_run
     with open(os.path.join(golden_dir, f"train_{name}.json")) as f:
@@ -530,6 +528,21 @@ def test_train_steps_match_oracle_and_reference(name, golden_dir):
         # the bf16 working copy is the rounded master
         assert torch.equal(dict(model.named_parameters())[k].detach().cpu(), w.to(torch.bfloat16)), k
     assert confident >= 0.1 * total, (confident, total)          # the comparison is not vacuous (measured: 26 %)
+
+
+def test_train_steps_at_a_small_rate_follow_the_bf16_working_weight_oracle():
+    """Four steps at lr 1e-4 (TRAIN_CASES hilbert32_1d_lr1e4: no overshoot) against the oracle run with the HIP path's weight
+    handling -- fp32 master, bf16 working copy (test_oracle_golden.oracle_train_run_bf16_working).  With the lag of the working
+    copy modelled, the trajectories stay together and the tolerances need no widening: loss 1 % and pre-clip gradient norm
+    2.5 % at EVERY step (the all-fp32 reference is 13 % away at step 2)."""
+    from test_oracle_golden import oracle_train_run_bf16_working
+    name = "hilbert32_1d_lr1e4"
+    ref_losses, ref_norms = oracle_train_run_bf16_working(name)
+    losses, norms, _, _ = _hip_train_run(name)
+    for s, (a, b) in enumerate(zip(losses, ref_losses)):
+        assert abs(a - b) <= 1e-2 * b, (s, losses, ref_losses)
+    for s, (a, b) in enumerate(zip(norms, ref_norms)):
+        assert abs(a / b - 1) <= 2.5e-2, (s, norms, ref_norms)
 
 
 def test_train_step_variants_are_bit_identical():
