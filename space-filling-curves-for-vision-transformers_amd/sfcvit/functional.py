@@ -170,9 +170,12 @@ def _traced():
     return torch.compiler.is_compiling()
 
 
-def pe_two_stage(x, pix):
-    """Gather + GEMM (default) or the fused kernels?  The GEMM wants 16-byte rows: P * C a multiple of 8."""
-    return PE_TWO_STAGE and (pix.shape[1] * x.shape[1]) % 8 == 0
+def pe_two_stage(x, pix, D):
+    """Gather + GEMM (default) or the fused kernels?  The GEMM wants 16-byte rows (P * C a multiple of 8), and the split only
+    pays where the projection is big enough to be GPU-bound: two launches forward and four backward instead of one and two
+    cost a launch-bound model more than the faster GEMM returns (CIFAR-size tokenizers: 0.3 GFLOP per pass)."""
+    K = pix.shape[1] * x.shape[1]
+    return PE_TWO_STAGE and K % 8 == 0 and 2.0 * x.shape[0] * pix.shape[0] * K * D >= 4e9
 
 
 def patch_embed(x, pix, weight, bias, desc=None):
@@ -182,7 +185,7 @@ def patch_embed(x, pix, weight, bias, desc=None):
     if _traced():
         from . import library
         return library.patch_embed(x, pix, _bf(weight), _bf(bias), desc)
-    if pe_two_stage(x, pix):
+    if pe_two_stage(x, pix, weight.shape[0]):
         return _PatchEmbed2.apply(x, pix, _bf(weight), _bf(bias))
     return _PatchEmbed.apply(x, pix, _bf(weight), _bf(bias), desc)
 

@@ -396,7 +396,7 @@ soft_ce_op.register_autograd(_ce_backward, setup_context=_ce_setup)
 # entry points used by sfcvit.functional when torch.compiler.is_compiling()
 # ----------------------------------------------------------------------------------------------------------------------
 def patch_embed(x, pix, weight, bias, desc):
-    if F.pe_two_stage(x, pix):
+    if F.pe_two_stage(x, pix, weight.shape[0]):
         return torch.ops.sfcvit.patch_embed2(x.contiguous(), pix, weight, bias)[0]
     meta = [desc.mode, desc.ncls, *desc.cnt] if desc is not None else []
     return torch.ops.sfcvit.patch_embed(x, pix, weight, bias, desc.dev if desc is not None else None, meta)[0]
