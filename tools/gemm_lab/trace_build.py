@@ -90,10 +90,39 @@ sub("""    if (wr == 0) bar();
             p8_trace[tid >> 8][i] = i < tr_n ? reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 8192)[(tid >> 8) * 256 + i] : 0ull;
     finish();
 }""" % TRACE_WG)
+if os.environ.get("TRACE_EPI"):
+    # TRACE_EPI=1: four more stamps per epilogue of the traced waves -- start | arithmetic done | LDS exchange done | stores
+    # issued -- into p8_trace_e[group][tile][4] (trace_epilogue.py prints them); a scheduling barrier pins each stamp
+    sub("namespace p8 {\n", """namespace p8 {
+__device__ unsigned long long p8_trace_e[2][60][4];
+#define P8_ESTAMP(k)                                                                                                 \\
+    do {                                                                                                             \\
+        __builtin_amdgcn_sched_barrier(0);                                                                           \\
+        if ((tid & 255) == 0 && blockIdx.x == %d && te_n < 60)                                                       \\
+            reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 12288)[((tid >> 8) * 60 + te_n) * 4 + (k)] = __builtin_amdgcn_s_memtime(); \\
+        __builtin_amdgcn_sched_barrier(0);                                                                           \\
+    } while (0)
+""" % TRACE_WG)
+    sub("    int tr_n = 0;\n", "    int tr_n = 0, te_n = 0;\n")
+    sub("        auto batch = [&](auto i0c, auto i1c) __attribute__((always_inline)) {\n            constexpr int i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;\n",
+        "        auto batch = [&](auto i0c, auto i1c) __attribute__((always_inline)) {\n            constexpr int i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;\n            if (i0 == 0) P8_ESTAMP(0);\n")
+    sub("            patch_exchange<i1 - i0>(pk, sm);\n", "            if (i0 == 0) P8_ESTAMP(1);\n            patch_exchange<i1 - i0>(pk, sm);\n            if (i0 == 0) P8_ESTAMP(2);\n")
+    sub("                store_row_pair(g, m0 + 16 * i, n0, sm, pk[i - i0][0], pk[i - i0][1]);\n            });\n        };",
+        "                store_row_pair(g, m0 + 16 * i, n0, sm, pk[i - i0][0], pk[i - i0][1]);\n            });\n            if (i0 == 0) { P8_ESTAMP(3); te_n++; }\n        };")
+    sub("            p8_trace[tid >> 8][i] = i < tr_n ? reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 8192)[(tid >> 8) * 256 + i] : 0ull;",
+        "            p8_trace[tid >> 8][i] = i < tr_n ? reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 8192)[(tid >> 8) * 256 + i] : 0ull;\n"
+        "    if ((tid & 255) == 0 && blockIdx.x == %d)\n        for (int i = 0; i < 240; i++)\n"
+        "            (&p8_trace_e[tid >> 8][0][0])[i] = i < 4 * te_n ? reinterpret_cast<unsigned long long *>(smem + LDS_BIAS + 12288)[(tid >> 8) * 240 + i] : 0ull;" % TRACE_WG)
 sub("    const int LDS_TOTAL = LDS_BIAS + (a.bias ? a.N * 2 : 0);", "    const int LDS_TOTAL = LDS_MAX;")
 src += """
 extern "C" int sfcvit_lab_trace(unsigned long long *host) {
     return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(sfcvit::p8::p8_trace), sizeof(unsigned long long) * 512));
+}
+"""
+if os.environ.get("TRACE_EPI"):
+    src += """
+extern "C" int sfcvit_lab_trace_epilogue(unsigned long long *host) {
+    return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(sfcvit::p8::p8_trace_e), sizeof(unsigned long long) * 480));
 }
 """
 tmp = os.path.join(CSRC, "build", "gemm8p_trace.hip")
