@@ -383,10 +383,11 @@ __global__ __launch_bounds__(RED_THREADS) void ln_bwd_reduce(const float *__rest
     }
 }
 
-// SFCVIT_LN_COLS=0: the 16-byte-vector kernel also at D = 768 (A/B in tools/bench_rowwise.py)
+// SFCVIT_LN_COLS=0: the 16-byte-vector kernel also at D = 768 / 1 024 (A/B in tools/bench_rowwise.py; at D = 1 024, ViT-L, the
+// float-pair form gains 2-6 %: 45.3 -> 44.6 us, with dropout output 61.4 -> 57.9 us at M = 36 864)
 bool ln_bwd_cols(int D) {
     static const bool on = [] { const char *e = getenv("SFCVIT_LN_COLS"); return !(e && e[0] == '0'); }();
-    return on && D == 768;
+    return on && (D == 768 || D == 1024);
 }
 
 // Workgroups of the backward kernel: two (16-byte-vector kernel, 190-222 registers) or three (column-chunk kernel, 145-156)
@@ -395,7 +396,7 @@ bool ln_bwd_cols(int D) {
 int ln_bwd_blocks(int M, int D) {
     const int want = (M + WAVES - 1) / WAVES;
     static const int env = [] { const char *e = getenv("SFCVIT_LN_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning knob
-    const int cap = env > 0 ? env : (ln_bwd_cols(D) ? 768 : 512);
+    const int cap = env > 0 ? env : (ln_bwd_cols(D) && D == 768 ? 768 : 512);    // (D = 1 024: 179-194 registers, two waves per SIMD)
     return want < cap ? want : cap;
 }
 
@@ -825,9 +826,12 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     float *part = static_cast<float *>(ws);
 #define LN_BWD(VPL) do { if (ap) hipLaunchKernelGGL((ln_bwd_kernel<VPL, true>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D); \
                          else hipLaunchKernelGGL((ln_bwd_kernel<VPL, false>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D); } while (0)
-    if (ln_bwd_cols(D)) {
+    if (ln_bwd_cols(D) && D == 768) {
         if (ap) hipLaunchKernelGGL((ln_bwd_cols_kernel<3, true>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M);
         else hipLaunchKernelGGL((ln_bwd_cols_kernel<3, false>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M);
+    } else if (ln_bwd_cols(D)) {
+        if (ap) hipLaunchKernelGGL((ln_bwd_cols_kernel<4, true>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M);
+        else hipLaunchKernelGGL((ln_bwd_cols_kernel<4, false>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M);
     } else if (D <= 512) LN_BWD(1);
     else if (D <= 1024) LN_BWD(2);
     else LN_BWD(4);

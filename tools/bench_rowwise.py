@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the row-wise kernels at the ViT-B step's shapes (M = 50176, D = 768): LayerNorm fwd / bwd,
-column sums.  Prints us per launch and the achieved HBM rate on the algorithmic bytes.
+"""Micro-benchmark of the row-wise kernels at the ViT-B step's shapes (M = 50176, D = 768; or `M D` on the command line):
+LayerNorm fwd / bwd, column sums.  Prints us per launch and the achieved HBM rate on the algorithmic bytes.
 SFCVIT_LN_BLOCKS=<n> changes the LayerNorm-backward grid (one process per setting)."""
 import os
 import sys
@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "space-filling-curves-for-vision-transform
 import torch  # noqa: E402
 from sfcvit import ops  # noqa: E402
 
-M, D = 50176, 768
+M, D = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (50176, 768)      # ViT-L: 36864 1024
 g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(M, D, device="cuda", generator=g).bfloat16()
 dy = torch.randn(M, D, device="cuda", generator=g).bfloat16()
