@@ -19,7 +19,7 @@ for p in ("p1", "p2"):
             k = row["Kernel_Name"]
             if "attn" not in k:
                 continue
-            k = k.split("(")[0].replace("void ", "").replace("sfcvit::(anonymous namespace)::", "")
+            k = k.replace("void ", "").replace("sfcvit::(anonymous namespace)::", "").split("(")[0]
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k in sorted(agg):
         print(p, k, {c: round(sum(v) / len(v)) for c, v in agg[k].items()})
