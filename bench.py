@@ -35,6 +35,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# dmabuf IPC is the only kind this pool's host driver supports: without it RCCL (and any cross-process sharing of
+# device memory) fails with "hipIpcGetMemHandle: invalid argument".  Must be in the environment before HIP initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "space-filling-curves-for-vision-transformers_amd"))
 

@@ -8,6 +8,10 @@
 
 namespace sfcvit {
 
+namespace tile_desc {          // sfcvit_tile_descriptors (tile_descriptors.cpp) <-> patch_embed_tiled.hip
+constexpr int MAXCLS = 8, DESC_HDR = 16;
+}
+
 // Records the message for sfcvit_last_error() and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();

@@ -14,6 +14,10 @@ import argparse
 import os
 import sys
 
+# dmabuf IPC is the only kind this pool's host driver supports: without it RCCL (and any cross-process sharing of
+# device memory) fails with "hipIpcGetMemHandle: invalid argument".  Must be in the environment before HIP initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -76,6 +80,9 @@ def main():
     ap.add_argument("--train-size", type=int, default=50000)
     ap.add_argument("--test-size", type=int, default=10000)
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--data-module", default=None,
+                    help="pkg.module:function returning (train_loader, test_loader) -- the caller's own DataLoaders in place "
+                         "of the reference's inline CIFAR-10 pipeline (main.py:169-230)")
     ap.add_argument("--checkpoint-dir", default="./vit_checkpoints")
     ap.add_argument("--resume", default=None)
     ap.add_argument("--resume-model-only", action="store_true",
@@ -101,15 +108,27 @@ def main():
         have_tv = True
     except ImportError:
         have_tv = False
-    if not a.synthetic and not have_tv:
-        print("torchvision is not installed: using --synthetic data")
-        a.synthetic = True
-    if not a.synthetic:
-        raise SystemExit("dataset loading is the reference's own (torchvision CIFAR-10, main.py:169-230); "
-                         "wire your DataLoader in here or pass --synthetic")
     per_rank = a.batch_size // world
-    train_loader = SyntheticLoader(a.train_size // world, per_rank, a.img_size, a.classes, seed + 1 + rank, device)
-    test_loader = SyntheticLoader(a.test_size // world, per_rank, a.img_size, a.classes, seed + 1001 + rank, device)
+    if a.data_module:
+        # The reference builds its loaders inline (main.py:169-230: torchvision CIFAR-10 + v2 transforms, DataLoader with
+        # 16 workers).  That pipeline is the caller's; this is the hook for it: `pkg.mod:fn` names a factory
+        #     fn(batch_size=, img_size=, classes=, rank=, world=, seed=) -> (train_loader, test_loader)
+        # returning iterables of (images [B, 3, H, W] float, labels [B] int64) with __len__, on any device (the loops move
+        # every batch to the GPU, src/training/train.py:144-145), each rank's own shard, every batch of `batch_size` rows.
+        import importlib
+        mod, _, fn = a.data_module.partition(":")
+        if not mod or not fn:
+            raise SystemExit("--data-module takes pkg.module:function")
+        factory = getattr(importlib.import_module(mod), fn)
+        train_loader, test_loader = factory(batch_size=per_rank, img_size=a.img_size, classes=a.classes, rank=rank,
+                                            world=world, seed=seed)
+    else:
+        if not a.synthetic:
+            print("no --data-module given (the reference's torchvision CIFAR-10 pipeline, main.py:169-230, is not part of "
+                  "this package" + ("" if have_tv else " and torchvision is not installed") + "): using --synthetic data")
+            a.synthetic = True
+        train_loader = SyntheticLoader(a.train_size // world, per_rank, a.img_size, a.classes, seed + 1 + rank, device)
+        test_loader = SyntheticLoader(a.test_size // world, per_rank, a.img_size, a.classes, seed + 1001 + rank, device)
 
     patch_embed = build_tokenizer(a)
     model = VisionTransformer1D(patch_embed=patch_embed, depth=a.depth, n_heads=a.heads, mlp_dim=a.mlp_dim,

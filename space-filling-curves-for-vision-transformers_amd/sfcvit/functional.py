@@ -49,7 +49,11 @@ def _slot(p):
         return None
     buf, off = slot
     if getattr(p, "_sfcvit_claimed", -1) == buf.epoch:
-        return None                               # second use of a shared parameter in one backward: autograd must add
+        # second use of a shared parameter in one backward: autograd must add.  It adds (first use's slot view + this
+        # use's fresh tensor) as soon as this use returns, i.e. it READS the slot now: a reduction the first use queued
+        # for the end of the pass (ops._Deferring) has to land before that.
+        ops.flush_deferred(end=False)
+        return None
     p._sfcvit_claimed = buf.epoch
     view = buf.flat_grad[off:off + p.numel()].view(p.shape)
     view._sfcvit_deferrable = True          # ops._Deferring: a reduction that ends here may wait for the end of the backward pass

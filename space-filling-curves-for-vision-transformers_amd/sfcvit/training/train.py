@@ -58,6 +58,10 @@ class GraphedTrainStep:
         cur.wait_stream(side)
         if snap is not None:
             self._restore(snap)
+            if reducer is not None:
+                # _restore put back THIS rank's pre-warm-up state, i.e. it undid the rank-0 broadcast of the reducer's
+                # first step: a rank that was built or loaded differently would drift again
+                reducer.sync_replicas()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None

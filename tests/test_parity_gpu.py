@@ -697,6 +697,62 @@ def test_shared_parameter_gradient_accumulates_once_per_use():
         assert w.grad.data_ptr() == opt.flat_grad.data_ptr() + 2 * opt.offsets[0]
 
 
+def test_shared_layernorm_and_mixer_parameters_with_deferred_reductions():
+    """a LayerNorm gamma / beta (and a mixer's vectors) used TWICE in one backward while their reductions are
+    deferred to the end of the pass: the second use makes autograd add (slot view + fresh tensor), which reads the slot --
+    functional._slot flushes the queue first.  Gradients must equal the ones computed with deferral switched off (bit for
+    bit: same kernels, same order) and agree with torch's fp32 autograd."""
+    import sfcvit.functional as F
+    from sfcvit import ops
+    from sfcvit.training import FusedAdamW
+    torch.manual_seed(5)
+    D = 256
+    dev = "cuda"
+    g = torch.nn.Parameter((1 + 0.1 * torch.randn(D)).to(dev, torch.bfloat16))
+    be = torch.nn.Parameter((0.1 * torch.randn(D)).to(dev, torch.bfloat16))
+    w1 = torch.nn.Parameter((torch.randn(2 * D, D) / 16).to(dev, torch.bfloat16))
+    b1 = torch.nn.Parameter((0.1 * torch.randn(2 * D)).to(dev, torch.bfloat16))
+    w2 = torch.nn.Parameter((torch.randn(D, 2 * D) / 22).to(dev, torch.bfloat16))
+    b2 = torch.nn.Parameter((0.1 * torch.randn(D)).to(dev, torch.bfloat16))
+    params = [g, be, w1, b1, w2, b2]
+    x = torch.randn(4, 128, D, device=dev).to(torch.bfloat16)
+    opt = FusedAdamW(params, lr=0.0, weight_decay=0.0, max_grad_norm=None)
+
+    def loss_hip(xt):
+        h = F.layer_norm(xt, g, be)
+        h = F.mixer_block(h, g, be, w1, b1, w2, b2)          # gamma / beta tied between the two LayerNorms
+        h = F.mixer_block(h, g, be, w1, b1, w2, b2)          # ... and the whole mixer used twice
+        return F.layer_norm(h, g, be).float().pow(2).mean()
+
+    def loss_ref(xt, ps):
+        gg, bb, a1, c1, a2, c2 = ps
+        ln = lambda t: torch.nn.functional.layer_norm(t, (D,), gg, bb, 1e-5)
+        mix = lambda t: t + torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(ln(t), a1, c1)), a2, c2)
+        return ln(mix(mix(ln(xt)))).pow(2).mean()
+    loss_hip(x).backward()
+    opt.step()                                   # builds the flat buffers (lr = 0: values unchanged)
+    grads = {}
+    saved = ops.DEFER_REDUCES
+    try:
+        for defer in (True, False):
+            ops.DEFER_REDUCES = defer
+            opt.zero_grad(set_to_none=True)
+            loss_hip(x).backward()
+            opt.adopt_all()
+            torch.cuda.synchronize()
+            assert ops.lib.sfcvit_reduce_pending() == 0
+            grads[defer] = [p.grad.detach().float().clone() for p in params]
+    finally:
+        ops.DEFER_REDUCES = saved
+    ref = [p.detach().float().requires_grad_(True) for p in params]
+    loss_ref(x.float(), ref).backward()
+    for name, a, b, r in zip("gamma beta w1 b1 w2 b2".split(), grads[True], grads[False], ref):
+        assert torch.equal(a, b), f"{name}: deferred and immediate reductions disagree"
+        ga, rr = a.flatten(), r.grad.flatten()
+        cos = float(torch.dot(ga, rr) / (ga.norm() * rr.norm()))
+        assert cos >= 0.995 and abs(float(ga.norm() / rr.norm()) - 1) <= 3e-2, (name, cos)
+
+
 def test_graphed_train_step_replays_bit_exactly_and_draws_new_masks():
     """GraphedTrainStep: the whole training step (training mode: dropout 0.1 / 0.5 on) captured into one hipGraph with
     the step state on the device (sfcvit_step_advance) must take the SAME steps as the same code run eagerly in
@@ -930,3 +986,21 @@ def test_torch_compile_traces_the_model_into_one_graph_and_matches_eager():
     torch.manual_seed(3)
     b = model(x)
     assert torch.equal(a, b)                                                     # same seeds, same masks as eager
+
+
+def test_main_py_trains_on_a_caller_supplied_dataloader(tmp_path):
+    """`main.py --data-module pkg:fn` takes the caller's loaders where the reference builds its torchvision
+    pipeline inline (/root/reference/main.py:169-230): one epoch on tests/data_module_example.py's CPU DataLoaders,
+    the reference's progress line (main.py:331-335) and a checkpoint with the reference's keys (main.py:345-354)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, os.path.join(root, "space-filling-curves-for-vision-transformers_amd", "main.py"), "--epochs", "1",
+           "--batch-size", "32", "--tokenizer", "hilbert", "--embed-dim", "64", "--depth", "2", "--heads", "2", "--mlp-dim", "128",
+           "--data-module", "data_module_example:loaders", "--checkpoint-dir", str(tmp_path)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Epoch 1/1 | Train Loss:" in out.stdout and "synthetic" not in out.stdout
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint_hilbert.pt"), map_location="cpu", weights_only=True)
+    assert {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "train_loss", "test_acc"} <= set(ck)
