@@ -149,6 +149,7 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     uint16_t *dbase = static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD;
     const int g = lane >> 4, li = lane & 15;
     const int key = 16 * kfi + li;                    // key waves: the key this lane's accumulator columns belong to
+    const uint32_t key_g = uint32_t(key) * DROP_G, dth32 = dth << 16;
     if (is_key) {                                     // rows >= N of the image copy row N - 1: those keys are masked below
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) kf[kk] = kc_frag_at(kimg, 16 * kfi, (k_off ^ (kk << 6)));
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
                 for (int r = 0; r < 4; r++) {
                     const float pv = fast_exp2(s[r] * c2 - lse4[r]);
                     float keep = 1.f;                                 // 1 / (1 - p) where the element is kept, else 0
-                    if (DROP)     // drop_keep2's flag of this lane's key: the 16-bit half (key & 1) of the pair hash, one v_bfe_u32
-                        keep = __builtin_amdgcn_ubfe(drop_pair_hash(rk4[r], uint32_t(key >> 1)), uint32_t(key & 1) * 16u, 16u) >= dth ? dsc : 0.f;
+                    if (DROP)     // element (query row, key): xor with the lane's key constant, one multiply, one compare
+                        keep = drop_hash_g(rk4[r], key_g) >= dth32 ? dsc : 0.f;
                     p[t][r] = pv * keep;
                     ds[t][r] = pv * (dp[r] * keep - del4[r]);             // x scale at the stores of dK and dQ
                 }

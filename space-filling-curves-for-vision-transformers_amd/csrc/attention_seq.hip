@@ -107,7 +107,9 @@ __global__ __launch_bounds__(THREADS, 3) void attn_seq_fwd_kernel(const sfcvit_a
 #pragma unroll
         for (int kf = 0; kf < MAXF; kf++)
             if (kf < nf) {
-                if (16 * kf + 16 > N) {                  // only the boundary fragment needs the key mask
+                // only the boundary fragment needs the key mask; with the fragment count known at compile time that is the
+                // last one (16 (NFC - 1) < N <= 16 NFC), and the other twelve carry no run-time test
+                if (NFC ? kf == NFC - 1 : 16 * kf + 16 > N) {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         if (16 * kf + 4 * (lane >> 4) + r >= N) s[kf][r] = -INFINITY;

@@ -76,34 +76,41 @@ __device__ __forceinline__ bf16x8 st_frag(const char *img, int col0, int kk, int
 }
 
 // ---- counter-based dropout mask ------------------------------------------------
-// Element (row, col) of a [rows, cols] tensor: one 32-bit hash per (row, col/2) pair gives two 16-bit
-// uniforms; keep iff u16 >= thresh, thresh = p * 65536.
-// The same function is evaluated in forward and backward (nothing is stored) and by
-// sfcvit_dropout_mask (tests).  Statistical quality: murmur3 finaliser of (pair, seed).
+// Element (row, col) of a [rows, cols] tensor is KEPT iff the top 16 bits of one 32-bit multiply-shift hash of
+// (row key, col) are >= thresh = p * 65536:
+//     keep(row, col) = ((row_key ^ col * 0x9E3779B1) * 0x2C1B3C6D) >= (thresh << 16)          [mod 2^32]
+// with row_key = a murmur3-finalised hash of (seed, row) worked out once per row.  The same function is evaluated in
+// forward and backward (nothing is stored) and by sfcvit_dropout_mask (tests).  Per element that is one xor, one 32-bit
+// multiply and one compare on top of col * G, which is a lane constant plus a literal in every kernel.
+// Rounds 1-3 drew TWO 16-bit uniforms from one xorshift-multiply-xorshift hash of (row key, col / 2): 6 vector
+// instructions per pair -- but per ELEMENT in the one-pass attention backward, where a lane holds one key and four queries
+// (different rows), and there the hash was 24 of the 50 vector instructions of a score tile (profiles/r4/attention_isa_budget.txt).
+// Statistics of the new mask (tools/dropout_mask_stats.py, 37 632 rows x 3 072 columns, p = 0.1 and 0.5): drop rate exact
+// to 1e-4, row and column rates binomially distributed, correlations at lags 1-2 along either axis and across seeds
+// within sampling noise (1e-4) -- the same figures as the old hash.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
-// Two-level form: a per-row key (once per row) and a cheap per-pair finaliser, so kernels that
-// walk along a row (attention: one query row per lane) pay ~5 integer ops per pair.
 __device__ __forceinline__ uint32_t drop_row_key(uint32_t seed, uint64_t row) {
     return mix32(uint32_t(row) * 0x9E3779B1u + mix32(seed ^ (uint32_t(row >> 32) * 0x7FEB352Du)));
 }
-__device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row_key, uint32_t pair_in_row) {
-    uint32_t x = row_key ^ (pair_in_row * 0x9E3779B1u);
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
-    return x;
-}
+constexpr uint32_t DROP_G = 0x9E3779B1u, DROP_C = 0x2C1B3C6Du;
+// hash of element `col` of the row with key `row_key`; col_g = col * DROP_G (callers that walk a row keep it as base + literal)
+__device__ __forceinline__ uint32_t drop_hash_g(uint32_t row_key, uint32_t col_g) { return (row_key ^ col_g) * DROP_C; }
+__device__ __forceinline__ uint32_t drop_hash(uint32_t row_key, uint32_t col) { return drop_hash_g(row_key, col * DROP_G); }
 // Effective seed of a dropout site: the by-value seed of the call plus the device-resident per-step offset (NULL = 0).
 // With the offset a captured hipGraph draws fresh masks on every replay (sfcvit_step_advance moves the offset), and
 // forward and backward of one step still agree (both read it between two advances).
 __device__ __forceinline__ uint32_t eff_seed(uint32_t seed, const uint32_t *off) { return off ? seed + *off : seed; }
+// thresh: 16-bit (p * 65536, p < 1); the kernels compare the 32-bit hash with thresh << 16 (drop_thresh32)
 __device__ __forceinline__ uint32_t drop_thresh(float p) { return uint32_t(p * 65536.f + 0.5f); }
-// keep flags of the two elements (cols 2*pair, 2*pair+1) of a row
+__device__ __forceinline__ bool drop_keep(uint32_t row_key, uint32_t col, uint32_t thresh) { return drop_hash(row_key, col) >= (thresh << 16); }
+// keep flags of the two elements (cols 2*pair, 2*pair+1) of a row (the interface of rounds 1-3: a pair per call)
 __device__ __forceinline__ void drop_keep2(uint32_t row_key, uint32_t pair_in_row, uint32_t thresh, bool &k0, bool &k1) {
-    const uint32_t h = drop_pair_hash(row_key, pair_in_row);
-    k0 = (h & 0xFFFFu) >= thresh;
-    k1 = (h >> 16) >= thresh;
+    const uint32_t g0 = pair_in_row * (2u * DROP_G), t32 = thresh << 16;
+    k0 = drop_hash_g(row_key, g0) >= t32;
+    k1 = drop_hash_g(row_key, g0 + DROP_G) >= t32;
 }
 
 // Wait states between the last MFMA of a sequence and the first VALU / LDS / store read of its
@@ -111,7 +118,18 @@ __device__ __forceinline__ void drop_keep2(uint32_t row_key, uint32_t pair_in_ro
 // across a taken branch (attention forward: `v_mfma ...; s_cbranch; v_max3 <acc>` read accumulators
 // two instructions after the MFMA and returned pre-MFMA values -- a run-to-run varying row max).
 // 16 states cover the 8-pass bf16 MFMAs; call it wherever control flow separates the two.
-__device__ __forceinline__ void mfma_fence() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
+// The sched_barriers are what makes it a fence: an asm statement, volatile and memory-clobbering as it may be, orders
+// memory operations, not MFMAs -- round 4 found three QK^T MFMAs of the forward kernel scheduled BEHIND the nops.  That round's
+// failure (whole query fragments of attn_seq_fwd_kernel<13, true> wrong, run to run, lse intact; tools/attn_fwd_repeat_check.py,
+// attn_fwd_race_probe.py) came and went with every change of the code between the MFMAs and the branches around them -- the
+// per-fragment run-time key-mask tests, exec-masked loads in front of the QK^T MFMAs -- and was 50x rarer with
+// -amdgpu-mfma-padding-ratio=100: hazards across basic-block boundaries next to MFMAs.  Rule kept since: no branch between
+// an MFMA and the first reader or overwriter of its operands; real fences at the phase boundaries.
+__device__ __forceinline__ void mfma_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // Compile-time loop: register arrays (MFMA accumulators, score rows) must only ever be indexed by constants; a loop
 // the unroller gives up on turns the index into a runtime value and the array into scratch memory.
