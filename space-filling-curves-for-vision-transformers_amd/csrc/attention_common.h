@@ -130,17 +130,34 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
-// Store a transposed accumulator: acc[hf][r] = X[row = lane&15][col = 16hf + 4g + r].
+// Store a transposed accumulator: acc[hf][r] = X[row = lane&15][col = 16hf + 4g + r] (g = lane >> 4), bf16, as TWO 16-byte
+// stores per lane.  Packed, a lane holds four 8-byte pieces (one per hf) that lie 32 bytes apart in its row; the piece
+// that continues it sits in the lane 16 further on.  v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows
+// of the second) on the pieces of an even / odd hf pair gives every lane 16 contiguous bytes:
+//     g even: pieces (h_even, g), (h_even, g + 1) -> columns 16 h_even + 8 (g >> 1) .. + 7
+//     g odd:  pieces (h_odd, g - 1), (h_odd, g)   -> columns 16 h_odd  + 8 (g >> 1) .. + 7
+// so a store instruction writes 16 rows x 64 contiguous bytes instead of 16 rows x 4 pieces of 8 bytes (rounds 1-3: four
+// 8-byte stores per lane).  Measured where it showed (round 4, stamped build of the one-pass backward): the 8 stores of a
+// key wave's dK / dV took ~2 200 clocks to issue and the 3-4 key waves of a SIMD issued theirs one after the other -- 7 000
+// clocks per (batch, head) in which nothing else ran.  All 64 lanes must be active (the swap crosses lanes); `valid` masks
+// the stores only.
 __device__ __forceinline__ void store_rows(uint16_t *__restrict__ dst, int ld, int row, bool valid, const f32x4 (&acc)[4],
                                            float mul, int lane) {
-    if (!valid) return;
+    uint32_t p[4][2];
 #pragma unroll
     for (int hf = 0; hf < 4; hf++) {
-        u32x2 o = {pack2bf(acc[hf][0] * mul, acc[hf][1] * mul), pack2bf(acc[hf][2] * mul, acc[hf][3] * mul)};
-        *reinterpret_cast<u32x2 *>(dst + size_t(row) * ld + 16 * hf + 4 * (lane >> 4)) = o;
+        p[hf][0] = pack2bf(acc[hf][0] * mul, acc[hf][1] * mul);
+        p[hf][1] = pack2bf(acc[hf][2] * mul, acc[hf][3] * mul);
+    }
+    const int g = lane >> 4;
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+        const auto lo = __builtin_amdgcn_permlane16_swap(p[2 * pr][0], p[2 * pr + 1][0], false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(p[2 * pr][1], p[2 * pr + 1][1], false, false);
+        const u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
+        if (valid) *reinterpret_cast<u32x4 *>(dst + size_t(row) * ld + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1)) = o;
     }
 }
-
 
 // Dropout keep-factors of 4 consecutive keys (key0 % 4 == 0) of the mask row with key `row_key`.
 __device__ __forceinline__ void drop_keep4(uint32_t row_key, int key0, uint32_t th, float sc, float (&keep)[4]) {

@@ -53,6 +53,19 @@ int raise_lds_limit(const void *kernel, int bytes, const char *what) {
     return SFCVIT_OK;
 }
 
+// Compute units of the current device (cached per device); 0 if it cannot be told.
+int device_cu_count() {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus[dev] = prop.multiProcessorCount;
+    }
+    return cus[dev];
+}
+
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SFCVIT_ELAUNCH, "%s: %s", what, hipGetErrorString(e));

@@ -17,6 +17,8 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();
 // hipGetLastError() -> SFCVIT_ELAUNCH with the HIP message, or SFCVIT_OK.
 int check_launch(const char *what);
+// Compute units of the current device (0 if unknown): the grid of the persistent kernels.
+int device_cu_count();
 // Opt a kernel into `bytes` of dynamic LDS on the current device (once per kernel and device; 0 or an error code).
 int raise_lds_limit(const void *kernel, int bytes, const char *what);
 

@@ -37,7 +37,7 @@ byt_f = B * N * 4 * H * 64 * 2
 byt_b = B * N * 8 * H * 64 * 2
 csum = torch.empty(3 * H * 64, device="cuda", dtype=torch.bfloat16)
 rows = {"fwd": [], "fwd tiled (SFCVIT_ATTN_LONG=0)": [], "bwd fused": [], "bwd fused + in_proj bias column sums (as in the training step)": [],
-        "bwd fused, no start-up stagger": [], "bwd two-kernel": [], "bwd two-kernel, tiled (SFCVIT_ATTN_LONG=0)": []}
+        "bwd fused, no start-up stagger": [], "bwd fused, one workgroup per item (SFCVIT_ATTN_BWD_PERSIST=0)": [], "bwd two-kernel": [], "bwd two-kernel, tiled (SFCVIT_ATTN_LONG=0)": []}
 for rnd in range(5):
     rows["fwd"].append(timeit(lambda: ops.attention_fwd(qkv, H, p, 5)))
     os.environ["SFCVIT_ATTN_LONG"] = "0"
@@ -49,6 +49,9 @@ for rnd in range(5):
     os.environ["SFCVIT_ATTN_STAGGER_BWD"] = "1,0"
     rows["bwd fused, no start-up stagger"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
     del os.environ["SFCVIT_ATTN_STAGGER_BWD"]
+    os.environ["SFCVIT_ATTN_BWD_PERSIST"] = "0"
+    rows["bwd fused, one workgroup per item (SFCVIT_ATTN_BWD_PERSIST=0)"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
+    os.environ["SFCVIT_ATTN_BWD_PERSIST"] = "1"
     os.environ["SFCVIT_ATTN_BWD_FUSED"] = "0"
     rows["bwd two-kernel"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
     os.environ["SFCVIT_ATTN_LONG"] = "0"
