@@ -28,6 +28,56 @@ import torch
 from . import curves as _curves
 
 
+# ----------------------------------------------------------------------------
+# rounding-point mode
+# ----------------------------------------------------------------------------
+# The HIP path keeps parameters and every activation it writes to HBM in bf16 and accumulates in fp32.  With
+# `rounding_points()` active the functions below round to bf16 at exactly those stores (and nowhere else), so that the
+# remaining HIP-vs-oracle difference is fp32 summation order plus the bf16 rounding of the *gradients* the backward
+# kernels store -- not the forward's rounding noise, which a 3e-2 tolerance against the fp32 oracle has to swallow.
+# Store points followed (product file: sfcvit/functional.py): gathered pixels and projected tokens (tokenizer), LN outputs,
+# the mixer's pre-GELU and GELU outputs, Q|K|V, the softmax numerators fed to P.V (csrc/attention_*.hip pack P to bf16
+# and divide by the fp32 row sum of the unrounded numerators), the attention output, each residual sum before its
+# LayerNorm, the ReLU hidden, the head's three GEMM outputs and its GELU, the logits.
+# Backward: rounding is treated as the identity (straight-through), i.e. the gradients are exact fp32 gradients of the
+# rounded forward, taken with respect to the bf16 parameter values.
+_ROUNDING = False
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _r(t):
+    return _RoundBF16.apply(t) if _ROUNDING else t
+
+
+class rounding_points:
+    """Context manager: `with vit_oracle.rounding_points(): logits = vit_oracle.forward(x, sd, cfg)`."""
+
+    def __enter__(self):
+        global _ROUNDING
+        self._was, _ROUNDING = _ROUNDING, True
+        return self
+
+    def __exit__(self, *exc):
+        global _ROUNDING
+        _ROUNDING = self._was
+        return False
+
+
+def _pre_gelu_is_stored(m, n, k):
+    """Whether the product's mixer stores the pre-activation in bf16 and applies GELU to the stored value (the shapes
+    its persistent GEMM takes, sfcvit/functional.py:_fast_gemm_shape) or applies GELU to the fp32 accumulator."""
+    return m >= 192 and n % 256 == 0 and k % 128 == 0 and k >= 256
+
+
 @dataclass
 class OracleConfig:
     tokenizer: str          # "hilbert1d" | "morton1d" | "raster1d" | "sfc"
@@ -113,7 +163,7 @@ def tokenize(x, sd, cfg, prefix="patch_embed."):
         t = tokens_sfc(x, sd[prefix + "sfc_indices"], cfg.pre_patch_size, cfg.patch_size)
     else:
         raise ValueError(cfg.tokenizer)
-    return t @ sd[prefix + "proj.weight"].t() + sd[prefix + "proj.bias"]
+    return _r(_r(t) @ sd[prefix + "proj.weight"].t() + sd[prefix + "proj.bias"])
 
 
 def hierarchical_tokens(x, sd, img_size, patch_size_list, curve, prefix=""):
@@ -238,22 +288,30 @@ def gelu_erf(x):
 def mixer_block(x, sd, prefix="mlp_mixer."):
     """vit.py:272: x + channel_mix(channel_mix_ln(x)); the token-mix branch is
     commented out in the reference (:269-271) and its parameters are unused."""
-    z = layer_norm(x, sd[prefix + "channel_mix_ln.weight"], sd[prefix + "channel_mix_ln.bias"])
-    h = gelu_erf(z @ sd[prefix + "channel_mix.0.weight"].t() + sd[prefix + "channel_mix.0.bias"])
-    return x + h @ sd[prefix + "channel_mix.2.weight"].t() + sd[prefix + "channel_mix.2.bias"]
+    z = _r(layer_norm(x, sd[prefix + "channel_mix_ln.weight"], sd[prefix + "channel_mix_ln.bias"]))
+    w1 = sd[prefix + "channel_mix.0.weight"]
+    u = z @ w1.t() + sd[prefix + "channel_mix.0.bias"]
+    if _pre_gelu_is_stored(z.numel() // z.shape[-1], w1.shape[0], w1.shape[1]):
+        u = _r(u)
+    h = _r(gelu_erf(u))
+    return _r(x + h @ sd[prefix + "channel_mix.2.weight"].t() + sd[prefix + "channel_mix.2.bias"])
 
 
 def attention(x, w_in, b_in, w_out, b_out, n_heads):
     b, n, d = x.shape
     hd = d // n_heads
-    qkv = x @ w_in.t() + b_in
+    qkv = _r(x @ w_in.t() + b_in)
     q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
     q = q.reshape(b, n, n_heads, hd).transpose(1, 2)
     k = k.reshape(b, n, n_heads, hd).transpose(1, 2)
     v = v.reshape(b, n, n_heads, hd).transpose(1, 2)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
-    p = torch.softmax(s, dim=-1)
-    o = (p @ v).transpose(1, 2).reshape(b, n, d)
+    if _ROUNDING:
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        o = (_r(e) @ v) / e.sum(dim=-1, keepdim=True)
+    else:
+        o = torch.softmax(s, dim=-1) @ v
+    o = _r(o.transpose(1, 2).reshape(b, n, d))
     return o @ w_out.t() + b_out
 
 
@@ -262,23 +320,25 @@ def encoder_layer(x, sd, prefix, n_heads):
     a = attention(x, sd[prefix + "self_attn.in_proj_weight"], sd[prefix + "self_attn.in_proj_bias"],
                   sd[prefix + "self_attn.out_proj.weight"], sd[prefix + "self_attn.out_proj.bias"],
                   n_heads)
-    x = layer_norm(x + a, sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"])
-    f = torch.relu(x @ sd[prefix + "linear1.weight"].t() + sd[prefix + "linear1.bias"])
+    x = _r(layer_norm(_r(x + a), sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"]))
+    f = _r(torch.relu(x @ sd[prefix + "linear1.weight"].t() + sd[prefix + "linear1.bias"]))
     f = f @ sd[prefix + "linear2.weight"].t() + sd[prefix + "linear2.bias"]
-    return layer_norm(x + f, sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"])
+    return _r(layer_norm(_r(x + f), sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"]))
 
 
 def head(x, sd, prefix="mlp_head."):
     """vit.py:303-319 with n_layers=2: LN -> FactorisedLinear -> GELU -> (Dropout) -> Linear."""
-    z = layer_norm(x, sd[prefix + "0.weight"], sd[prefix + "0.bias"])
-    h = torch.einsum("bnd,rd->bnr", z, sd[prefix + "1.W_emb"])
-    y = torch.einsum("bnr,onr->bo", h, sd[prefix + "1.W_seq"])
-    y = gelu_erf(y)
-    return y @ sd[prefix + "4.weight"].t() + sd[prefix + "4.bias"]
+    z = _r(layer_norm(x, sd[prefix + "0.weight"], sd[prefix + "0.bias"]))
+    h = _r(torch.einsum("bnd,rd->bnr", z, sd[prefix + "1.W_emb"]))
+    y = _r(torch.einsum("bnr,onr->bo", h, sd[prefix + "1.W_seq"]))
+    y = _r(gelu_erf(y))
+    return _r(y @ sd[prefix + "4.weight"].t() + sd[prefix + "4.bias"])
 
 
 def forward(x, sd, cfg, return_intermediates=False):
     inter = {}
+    if _ROUNDING:                                   # the product's parameters are bf16 tensors
+        sd = {k: (_r(v) if torch.is_floating_point(v) else v) for k, v in sd.items()}
     t = tokenize(x, sd, cfg)
     inter["tokens"] = t
     if cfg.variant == "1d":

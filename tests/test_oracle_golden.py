@@ -178,18 +178,49 @@ def _full_cases():
     return sorted(FULL_CASES)
 
 
-def oracle_full_pass(name):
-    """(cfg, batch, leaves, logits, loss) of the oracle on the formula state of a FULL_CASES entry, gradients populated."""
+def oracle_full_pass(name, rounded=False):
+    """(cfg, batch, leaves, logits, loss) of the oracle on the formula state of a FULL_CASES entry, gradients populated.
+    rounded=True: the oracle's rounding-point mode (bf16 at the stores of the HIP path, fp32 accumulation)."""
+    import contextlib
     from oracle.cases import FULL_CASES
     cfg, batch = FULL_CASES[name]
     sd = vit_oracle.formula_state(cfg)
     leaves = {k: v.requires_grad_(True) for k, v in vit_oracle.trainable(sd).items()}
     x = formula.image_batch(batch, cfg.in_channels, cfg.img_size, cfg.img_size)
     tgt = formula.soft_targets(batch, cfg.num_classes)
-    logits = vit_oracle.forward(x, sd, cfg)
-    loss = vit_oracle.soft_target_ce(logits, tgt)
-    loss.backward()
+    with (vit_oracle.rounding_points() if rounded else contextlib.nullcontext()):
+        logits = vit_oracle.forward(x, sd, cfg)
+        loss = vit_oracle.soft_target_ce(logits, tgt)
+        loss.backward()
     return cfg, batch, sd, leaves, logits.detach(), loss.detach()
+
+
+@pytest.mark.parametrize("name", ["vit_tiny_raster32", "vit_l_hilbert384"])
+def test_rounding_point_mode_differs_from_fp32_by_bf16_noise_only(name):
+    """The oracle's rounding-point mode (bf16 where the HIP path stores bf16, fp32 accumulation, straight-through
+    backward) against the fp32 oracle it is derived from: the two must differ (the mode is on), by no more than the
+    tolerance the fp32 comparison of the HIP path has always stated (3e-2 * max|logit|, gradient cosine >= 0.99), and
+    outside the mode the functions are the fp32 ones bit for bit."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    cfg, batch, sd, leaves, logits, loss = oracle_full_pass(name)
+    _, _, _, rleaves, rlogits, rloss = oracle_full_pass(name, rounded=True)
+    assert not vit_oracle._ROUNDING
+    err = float((rlogits - logits).abs().max() / logits.abs().max())
+    assert 1e-5 < err <= 3e-2, err
+    assert torch.equal(rlogits, rlogits.to(torch.bfloat16).float())          # the logits themselves are a bf16 store
+    assert abs(float(rloss) - float(loss)) <= 5e-3 * abs(float(loss)) + 2e-3
+    worst = 1.0
+    for k, v in leaves.items():
+        if v.grad is None:
+            assert rleaves[k].grad is None, k
+            continue
+        g, r = rleaves[k].grad.flatten(), v.grad.flatten()
+        if float(r.norm()) < 1e-7:
+            continue
+        worst = min(worst, float(torch.dot(g, r) / (g.norm() * r.norm())))
+    assert worst >= 0.99, worst
+    _, _, _, _, again, _ = oracle_full_pass(name)
+    assert torch.equal(again, logits)
 
 
 @pytest.mark.parametrize("name", _full_cases())
