@@ -289,6 +289,9 @@ int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const float *mean, 
 /* grads_bf16 != 0: dgamma / dbeta / dcol are bf16 [D] instead of fp32 -- the caller passes views of its flat
  * gradient buffer and no cast / accumulate pass follows. */
 int64_t sfcvit_layernorm_bwd_ws(int M, int D);
+/* HOST: name of the main kernel the calling thread's last sfcvit_layernorm_bwd / _bwd_drop launched, as rocprofv3 prints
+ * it (e.g. "ln_bwd_cols_kernel<4, true>"): tests assert through it that a width ran on the column-sum kernel. */
+int sfcvit_last_rowwise_kernel(char *buf, int n);
 
 /* ------------------------------------------------------------------------
  * Multi-head self-attention core (no mask) on the packed projection

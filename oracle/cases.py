@@ -110,6 +110,10 @@ FULL_CASES = {
                                       num_classes=1000, variant="1d"), 2),
     "vit_l_raster384": (OracleConfig("raster1d", 384, 256, 3, 1024, depth=2, n_heads=16, mlp_dim=4096,
                                      num_classes=1000, variant="1d"), 2),
+    # ViT-L launch geometry pinned to the reference: M = 16 * 576 = 9 216 rows take the persistent GEMM, the column-sum
+    # LayerNorm backward at D = 1 024 and the long-sequence attention kernels
+    "vit_l_hilbert384_b16": (OracleConfig("hilbert1d", 384, 256, 3, 1024, depth=2, n_heads=16, mlp_dim=4096,
+                                          num_classes=1000, variant="1d"), 16),
 }
 
 # name -> (model case, steps, lr, weight_decay): optimisation steps of the reference's loop body

@@ -8,6 +8,14 @@ namespace {
 thread_local char g_err[512] = "";
 thread_local int g_gemm[5] = {0, 0, 0, 0, 0};
 thread_local char g_attn[96] = "none";
+thread_local char g_rowwise[96] = "none";
+}
+
+void note_rowwise_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_rowwise, sizeof(g_rowwise), fmt, ap);
+    va_end(ap);
 }
 
 void note_attn_kernel(const char *fmt, ...) {
@@ -95,6 +103,12 @@ extern "C" int sfcvit_last_gemm_kernel(char *buf, int n) {
 extern "C" int sfcvit_last_attn_kernel(char *buf, int n) {
     if (!buf || n <= 0) return SFCVIT_EINVAL;
     snprintf(buf, size_t(n), "%s", sfcvit::g_attn);
+    return SFCVIT_OK;
+}
+
+extern "C" int sfcvit_last_rowwise_kernel(char *buf, int n) {
+    if (!buf || n <= 0) return SFCVIT_EINVAL;
+    snprintf(buf, size_t(n), "%s", sfcvit::g_rowwise);
     return SFCVIT_OK;
 }
 

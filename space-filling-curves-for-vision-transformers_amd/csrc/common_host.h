@@ -28,6 +28,8 @@ void note_gemm_kernel(int family, int a = 0, int b = 0, int c = 0, int d = 0);
 // Which attention kernel the calling thread's last sfcvit_attention_fwd / _bwd launched (its main kernel, named as
 // rocprofv3 names it); fmt is printf-style.
 void note_attn_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+// Which row-wise kernel the calling thread's last sfcvit_layernorm_bwd* launched (sfcvit_last_rowwise_kernel).
+void note_rowwise_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 bool gemm_fused_colsum();     // the kernel noted last was the 8-phase kernel with column sums in its epilogue
 bool gemm_fused_actmask();    // ... with the activation bit mask written (act) or read (dact) by its epilogue
 

@@ -338,8 +338,128 @@ __global__ __launch_bounds__(2 * GT) void tokens_gather_p256_kernel(const void *
     }
 }
 
+
+// Tokens that are 16 x 16 pixel tiles of an fp32 image (every Hilbert / Z tokenizer at 256 pixels per token): the image is
+// read in WHOLE 128-byte lines -- a line is one tile row of two horizontally adjacent tiles -- with 16-byte loads, eight
+// lines per wave instruction, and the curve order is applied on the way OUT of LDS.  One wave owns a unit = (tile pair,
+// image): 2 C wave loads, the bf16 pair image [C][16 rows][32 pixels] in a wave-private LDS region, then every lane
+// collects the 8 features of each of its C output vectors with 2-byte LDS reads at addresses worked out once per
+// workgroup (feature j of token t: channel j % C of curve pixel j / C), and the two token rows leave as contiguous
+// 16-byte stores.  Against the per-pixel kernel above: a quarter of the load instructions, half the lines touched per
+// byte (a 4-byte-per-lane load of 64 curve-consecutive pixels touches 8 lines for 256 bytes), no workgroup barrier
+// between a unit's loads and its stores.  Workgroup = 4 waves x 2 images, both images' loads in flight before the first
+// is stored.
+constexpr int TG_THREADS = 256, TG_IMG = 8;
+
+template <int C>
+__global__ __launch_bounds__(TG_THREADS) void tokens_gather_tiles_kernel(const float *__restrict__ x, const int32_t *__restrict__ pix,
+                                                                         const int32_t *__restrict__ order, const int32_t *__restrict__ origin,
+                                                                         uint16_t *__restrict__ tokens, int B, int HW, int W,
+                                                                         uint32_t wmagic, int N) {
+    extern __shared__ __attribute__((aligned(16))) char smem_g[];
+    uint16_t *pos = reinterpret_cast<uint16_t *>(smem_g);                  // [2 tokens][256 curve pixels] -> pixel of the pair image
+    constexpr int UNIT = C * 16 * 64;                                      // bytes of one bf16 pair image
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int slot = 2 * blockIdx.x;
+    const bool two = slot + 1 < N;
+    const int n0 = order ? order[slot] : slot;
+    const int n1 = two ? (order ? order[slot + 1] : slot + 1) : n0;
+    const int o0 = origin[n0], o1 = origin[n1];
+    for (int i = tid; i < 512; i += TG_THREADS) {
+        const int t = i >> 8, kk = i & 255;
+        const uint32_t d = uint32_t(pix[size_t(t ? n1 : n0) * 256 + kk] - (t ? o1 : o0));     // < 16 W
+        const uint32_t r = __umulhi(d, wmagic);                           // d / W: exact for d W < 2^32
+        pos[i] = uint16_t(r * 32 + 16 * t + (d - r * W));
+    }
+    // this wave's two images: every line of the pair's rows, all loads in flight
+    const int b0 = blockIdx.y * TG_IMG + 2 * wave;
+    const int chunk = lane & 7, lt = chunk >> 2;
+    const size_t src0 = size_t(lt ? o1 : o0) + 4 * (chunk & 3);
+    f32x4 v[2][2 * C];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (b0 + u < B) {
+            const float *im = x + size_t(b0 + u) * C * HW + src0;
+#pragma unroll
+            for (int i = 0; i < 2 * C; i++) {
+                const int line = 8 * i + (lane >> 3);
+                v[u][i] = *reinterpret_cast<const f32x4 *>(im + size_t(line >> 4) * HW + size_t(line & 15) * W);
+            }
+        }
+    }
+    __syncthreads();
+    // byte addresses of the features of this lane's output vectors (vector vv of the pair = lane + 64 i: token vv / (32 C),
+    // features 8 (vv % (32 C)) ... + 8)
+    uint32_t addr[C][8];
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+        const int vv = lane + 64 * i, t = vv / (32 * C), j0 = (vv - t * 32 * C) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int j = j0 + e, kk = j / C, c = j - kk * C;
+            addr[i][e] = uint32_t(c) * 1024 + 2 * uint32_t(pos[t * 256 + kk]);
+        }
+    }
+    char *mine = smem_g + 1024 + size_t(2 * wave) * UNIT;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (b0 + u >= B) break;                                            // wave-uniform
+        char *im = mine + u * UNIT;
+#pragma unroll
+        for (int i = 0; i < 2 * C; i++) {
+            const int line = 8 * i + (lane >> 3);
+            u32x2 pk;
+            pk[0] = pack2bf(v[u][i][0], v[u][i][1]);
+            pk[1] = pack2bf(v[u][i][2], v[u][i][3]);
+            *reinterpret_cast<u32x2 *>(im + line * 64 + chunk * 8) = pk;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+            const int vv = lane + 64 * i, t = vv / (32 * C), j0 = (vv - t * 32 * C) * 8;
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t lo = *reinterpret_cast<const uint16_t *>(im + addr[i][2 * q]);
+                const uint32_t hi = *reinterpret_cast<const uint16_t *>(im + addr[i][2 * q + 1]);
+                o[q] = lo | (hi << 16);
+            }
+            if (t == 0 || two)
+                *reinterpret_cast<u32x4 *>(tokens + (size_t(b0 + u) * N + (t ? n1 : n0)) * (256 * C) + j0) = o;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace sfcvit
+
+extern "C" int sfcvit_tokens_gather_tiles(const void *x, const int32_t *pix, const int32_t *order, const int32_t *origin, int B, int C,
+                                          int H, int W, int N, void *tokens, int ld, void *stream) {
+    using namespace sfcvit;
+    if (!x || !pix || !origin || !tokens) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: null pointer");
+    if (B <= 0 || C < 1 || C > 4 || H <= 0 || W <= 0 || N <= 0 || int64_t(N) * 256 != int64_t(H) * W || (W & 7) || (H & 15))
+        return fail(SFCVIT_EINVAL, "tokens_gather_tiles: B=%d C=%d H=%d W=%d N=%d (1 <= C <= 4, W %% 8 == 0, H %% 16 == 0, N * 256 == H * W)", B, C, H, W, N);
+    if (ld != 256 * C) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: ld=%d (must be 256 * C = %d)", ld, 256 * C);
+    if (!aligned16(x) || !aligned16(tokens)) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: x and tokens must be 16-byte aligned");
+    if (int64_t(16) * W * W >= (int64_t(1) << 32)) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: W=%d too wide", W);
+    const dim3 grid((N + 1) / 2, (B + TG_IMG - 1) / TG_IMG);
+    if (grid.y > 65535) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: batch %d too large", B);
+    const uint32_t wmagic = uint32_t((uint64_t(1) << 32) / uint32_t(W)) + 1;
+    const size_t lds = 1024 + size_t(8) * C * 1024;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const auto *xp = static_cast<const float *>(x);
+    auto *tp = static_cast<uint16_t *>(tokens);
+    const int HW = H * W;
+    switch (C) {
+    case 1: hipLaunchKernelGGL(tokens_gather_tiles_kernel<1>, grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); break;
+    case 2: hipLaunchKernelGGL(tokens_gather_tiles_kernel<2>, grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); break;
+    case 3: hipLaunchKernelGGL(tokens_gather_tiles_kernel<3>, grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); break;
+    default: hipLaunchKernelGGL(tokens_gather_tiles_kernel<4>, grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); break;
+    }
+    return check_launch("tokens_gather_tiles");
+}
 
 extern "C" int sfcvit_tokens_gather(const void *x, int x_is_bf16, const int32_t *pix, const int32_t *order, int B, int C, int HW, int N,
                                     int P, void *tokens, int ld, void *stream) {

@@ -826,6 +826,9 @@ extern "C" int sfcvit_layernorm_bwd_drop(const void *dy, const void *x, const fl
     float *part = static_cast<float *>(ws);
 #define LN_BWD(VPL) do { if (ap) hipLaunchKernelGGL((ln_bwd_kernel<VPL, true>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D); \
                          else hipLaunchKernelGGL((ln_bwd_kernel<VPL, false>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M, D); } while (0)
+    const char *tf = ap ? "true" : "false";
+    if (ln_bwd_cols(D)) note_rowwise_kernel("ln_bwd_cols_kernel<%d, %s>", D == 768 ? 3 : 4, tf);
+    else note_rowwise_kernel("ln_bwd_kernel<%d, %s>", D <= 512 ? 1 : D <= 1024 ? 2 : 4, tf);
     if (ln_bwd_cols(D) && D == 768) {
         if (ap) hipLaunchKernelGGL((ln_bwd_cols_kernel<3, true>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M);
         else hipLaunchKernelGGL((ln_bwd_cols_kernel<3, false>), grid, block, lds, s, dyp, xp, mean, rstd, gp, ap, dxp, ddp, p, seed, seed_off, part, M);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "sfcvit_gemm_colsum_workspace": (c_int64, [c_int, c_int]),
     "sfcvit_last_gemm_kernel": (c_int, [ctypes.c_char_p, c_int]),
     "sfcvit_last_attn_kernel": (c_int, [ctypes.c_char_p, c_int]),
+    "sfcvit_last_rowwise_kernel": (c_int, [ctypes.c_char_p, c_int]),
     "sfcvit_colsum_workspace": (c_int64, [c_int, c_int]),
     "sfcvit_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "sfcvit_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

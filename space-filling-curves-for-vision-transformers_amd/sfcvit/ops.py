@@ -64,6 +64,12 @@ def last_attn_kernel():
     return buf.value.decode()
 
 
+def last_rowwise_kernel():
+    buf = ctypes.create_string_buffer(96)
+    lib.sfcvit_last_rowwise_kernel(buf, 96)
+    return buf.value.decode()
+
+
 def _launch(key, work, fn):
     out = fn() if TIMER is None else TIMER.launch(key, work, fn)
     if KERNEL_LOG is not None:
@@ -398,6 +404,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=None, drop_p=0.0, drop_seed=0
                                             int(gdt == _BF16), M, D, _p(ws),
                                             _stream()),
               "sfcvit_layernorm_bwd")
+    if KERNEL_LOG is not None:
+        KERNEL_LOG.append(last_rowwise_kernel())
     out = (dx, dg, db) + ((dx_drop,) if drop_p > 0 else ()) + ((dcol,) if want_colsum else ())
     return out
 
