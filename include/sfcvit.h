@@ -120,6 +120,12 @@ int sfcvit_patch_embed_fwd(const sfcvit_patch_embed_args *a, void *stream);
  * ViT-B the persistent GEMMs run the projection and its weight gradient 2-3x faster than the fused gather kernels). */
 int sfcvit_tokens_gather(const void *x, int x_is_bf16, const int32_t *pix, const int32_t *order, int B, int C, int HW, int N, int P,
                          void *tokens, int ld, void *stream);
+/* The same tokens for pixel tables whose tokens are 16 x 16 pixel tiles of an fp32 image (sfcvit_tile_descriptors mode 1:
+ * every Hilbert / Z tokenizer at 256 pixels per token): whole 128-byte image lines by 16-byte loads, the curve order applied on
+ * the way out of LDS (round 4; csrc/patch_embed.hip tokens_gather_tiles_kernel).  origin (device, [N]) = flat offset of each
+ * token's top-left pixel (descriptor words [16 + N, 16 + 2 N)); order as above; ld must be 256 * C, 1 <= C <= 4, x fp32. */
+int sfcvit_tokens_gather_tiles(const void *x, const int32_t *pix, const int32_t *order, const int32_t *origin, int B, int C, int H,
+                               int W, int N, void *tokens, int ld, void *stream);
 /* dW = sum_{b,t} dY[b,t,:]^T tokens[b,t,:] with the tokens re-gathered from x
  * (nothing but x is saved for backward); the image receives no gradient. */
 int sfcvit_patch_embed_bwd(const sfcvit_patch_embed_args *a, void *stream);

@@ -108,13 +108,12 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     const bool is_key = wave < nf || (split && wave == nf), is_dq = wave >= FWAVES - 2;
     const uint32_t dth = drop_thresh(a.dropout_p);
     const float scale = a.scale, c2 = a.scale * 1.4426950408889634f;
-    // lane offsets of the fragment reads: the XOR swizzle commutes with the fragment index, so ONE register per kind
-    // (k_off ^ (kk << 6), t_off ^ (hf << 5)) instead of the six of LaneOff -- the register file is full
-    const int k_off = lane_offsets(lane).k[0], t_off = lane_offsets(lane).t[0];
+    // (lane offsets of the fragment reads are rebuilt inside key_step / dq_step from an opaque lane id: hoisted here they
+    // were spilled and reloaded every step)
     const float dsc = 1.f / (1.f - a.dropout_p);
     const int g = lane >> 4, li = lane & 15;
     const int key = 16 * kfi + li;                    // key waves: the key this lane's accumulator columns belong to
-    const uint32_t key_g = uint32_t(key) * DROP_G, dth32 = dth << 16;
+    const uint32_t dth32 = dth << 16;
 
     // what an item needs in registers / the small arrays before its loop: V fragments (key waves), the O pieces that pair
     // with this thread's pieces of the dO image (delta), lse and the dropout row keys.  For the first item this runs in
@@ -359,7 +358,7 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
             else dma_piece(doimg, reinterpret_cast<const uint16_t *>(rec_next[1]), D, p);
         }
     };
-    int tr_i = ((item - int(blockIdx.x)) / int(gridDim.x)) * 16;
+    [[maybe_unused]] int tr_i = ((item - int(blockIdx.x)) / int(gridDim.x)) * 16;
     ATRACE(tr_i);
     for (int c = 0; c < nc; c++) {
         if (has_next && c >= 1) prefetch(c);

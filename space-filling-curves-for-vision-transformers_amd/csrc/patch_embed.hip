@@ -347,11 +347,14 @@ __global__ __launch_bounds__(2 * GT) void tokens_gather_p256_kernel(const void *
 // workgroup (feature j of token t: channel j % C of curve pixel j / C), and the two token rows leave as contiguous
 // 16-byte stores.  Against the per-pixel kernel above: a quarter of the load instructions, half the lines touched per
 // byte (a 4-byte-per-lane load of 64 curve-consecutive pixels touches 8 lines for 256 bytes), no workgroup barrier
-// between a unit's loads and its stores.  Workgroup = 4 waves x 2 images, both images' loads in flight before the first
-// is stored.
-constexpr int TG_THREADS = 256, TG_IMG = 8;
+// between a unit's loads and its stores.  Workgroup = 4 waves x U images (U = 1: 78 registers, six workgroups per CU, 6 272
+// short workgroups at ViT-B / 256 images -- the tail of the launch is what U = 2 lost: 45.7 vs 44.0 us in the step); the
+// image is read and the tokens are written with nontemporal accesses (see the launch code).  A third form -- one workgroup
+// per 16-row strip of the image, read front to back -- was built and dropped: 56 us warm against 38 (two barriers per image,
+// 132 registers).
+constexpr int TG_THREADS = 256;
 
-template <int C>
+template <int C, int NT, int U>
 __global__ __launch_bounds__(TG_THREADS) void tokens_gather_tiles_kernel(const float *__restrict__ x, const int32_t *__restrict__ pix,
                                                                          const int32_t *__restrict__ order, const int32_t *__restrict__ origin,
                                                                          uint16_t *__restrict__ tokens, int B, int HW, int W,
@@ -372,18 +375,19 @@ __global__ __launch_bounds__(TG_THREADS) void tokens_gather_tiles_kernel(const f
         pos[i] = uint16_t(r * 32 + 16 * t + (d - r * W));
     }
     // this wave's two images: every line of the pair's rows, all loads in flight
-    const int b0 = blockIdx.y * TG_IMG + 2 * wave;
+    const int b0 = blockIdx.y * (4 * U) + U * wave;
     const int chunk = lane & 7, lt = chunk >> 2;
     const size_t src0 = size_t(lt ? o1 : o0) + 4 * (chunk & 3);
-    f32x4 v[2][2 * C];
+    f32x4 v[U][2 * C];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         if (b0 + u < B) {
             const float *im = x + size_t(b0 + u) * C * HW + src0;
 #pragma unroll
             for (int i = 0; i < 2 * C; i++) {
                 const int line = 8 * i + (lane >> 3);
-                v[u][i] = *reinterpret_cast<const f32x4 *>(im + size_t(line >> 4) * HW + size_t(line & 15) * W);
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(im + size_t(line >> 4) * HW + size_t(line & 15) * W);
+                v[u][i] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
             }
         }
     }
@@ -400,9 +404,9 @@ __global__ __launch_bounds__(TG_THREADS) void tokens_gather_tiles_kernel(const f
             addr[i][e] = uint32_t(c) * 1024 + 2 * uint32_t(pos[t * 256 + kk]);
         }
     }
-    char *mine = smem_g + 1024 + size_t(2 * wave) * UNIT;
+    char *mine = smem_g + 1024 + size_t(U * wave) * UNIT;
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         if (b0 + u >= B) break;                                            // wave-uniform
         char *im = mine + u * UNIT;
 #pragma unroll
@@ -426,8 +430,11 @@ __global__ __launch_bounds__(TG_THREADS) void tokens_gather_tiles_kernel(const f
                 const uint32_t hi = *reinterpret_cast<const uint16_t *>(im + addr[i][2 * q + 1]);
                 o[q] = lo | (hi << 16);
             }
-            if (t == 0 || two)
-                *reinterpret_cast<u32x4 *>(tokens + (size_t(b0 + u) * N + (t ? n1 : n0)) * (256 * C) + j0) = o;
+            if (t == 0 || two) {
+                u32x4 *dst = reinterpret_cast<u32x4 *>(tokens + (size_t(b0 + u) * N + (t ? n1 : n0)) * (256 * C) + j0);
+                if (NT & 2) __builtin_nontemporal_store(o, dst);
+                else *dst = o;
+            }
         }
     }
 }
@@ -444,20 +451,32 @@ extern "C" int sfcvit_tokens_gather_tiles(const void *x, const int32_t *pix, con
     if (ld != 256 * C) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: ld=%d (must be 256 * C = %d)", ld, 256 * C);
     if (!aligned16(x) || !aligned16(tokens)) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: x and tokens must be 16-byte aligned");
     if (int64_t(16) * W * W >= (int64_t(1) << 32)) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: W=%d too wide", W);
-    const dim3 grid((N + 1) / 2, (B + TG_IMG - 1) / TG_IMG);
-    if (grid.y > 65535) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: batch %d too large", B);
-    const uint32_t wmagic = uint32_t((uint64_t(1) << 32) / uint32_t(W)) + 1;
-    const size_t lds = 1024 + size_t(8) * C * 1024;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const auto *xp = static_cast<const float *>(x);
     auto *tp = static_cast<uint16_t *>(tokens);
     const int HW = H * W;
+    static const int upw = [] { const char *e = getenv("SFCVIT_GATHER_U"); return e && atoi(e) == 2 ? 2 : 1; }();   // images per wave (A/B: 2 = fewer, longer workgroups)
+    const dim3 grid((N + 1) / 2, (B + 4 * upw - 1) / (4 * upw));
+    if (grid.y > 65535) return fail(SFCVIT_EINVAL, "tokens_gather_tiles: batch %d too large", B);
+    const uint32_t wmagic = uint32_t((uint64_t(1) << 32) / uint32_t(W)) + 1;
+    const size_t lds = 1024 + size_t(4 * upw) * C * 1024;
+    // nontemporal loads (1) and stores (2).  The gather is the first kernel of a step: L2 and the memory-side cache are full
+    // of the optimizer's dirty lines, and every line an ordinary load allocates evicts one of them -- a write-back that
+    // shares HBM with the gather (75.8 us against 42.1 us with clean caches; a plain fp32 -> bf16 cast of the image suffers
+    // the same: 69 vs 37 us).  Streaming loads do not allocate: 46.0 us; with streaming stores 43.2 us alone, 44.0 us in
+    // the step (profiles/r4/gather_ab.txt).  SFCVIT_GATHER_NT=0..3 for the A/B.
+    static const int nt = [] { const char *e = getenv("SFCVIT_GATHER_NT"); return e ? atoi(e) : 3; }();
+#define TILES(CC, NTV) do { if (upw == 2) hipLaunchKernelGGL((tokens_gather_tiles_kernel<CC, NTV, 2>), grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); \
+                            else hipLaunchKernelGGL((tokens_gather_tiles_kernel<CC, NTV, 1>), grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); } while (0)
+#define TILES_C(CC) do { if (nt == 1) TILES(CC, 1); else if (nt == 2) TILES(CC, 2); else if (nt == 3) TILES(CC, 3); else TILES(CC, 0); } while (0)
     switch (C) {
-    case 1: hipLaunchKernelGGL(tokens_gather_tiles_kernel<1>, grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); break;
-    case 2: hipLaunchKernelGGL(tokens_gather_tiles_kernel<2>, grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); break;
-    case 3: hipLaunchKernelGGL(tokens_gather_tiles_kernel<3>, grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); break;
-    default: hipLaunchKernelGGL(tokens_gather_tiles_kernel<4>, grid, dim3(TG_THREADS), lds, s, xp, pix, order, origin, tp, B, HW, W, wmagic, N); break;
+    case 1: TILES_C(1); break;
+    case 2: TILES_C(2); break;
+    case 3: TILES_C(3); break;
+    default: TILES_C(4); break;
     }
+#undef TILES_C
+#undef TILES
     return check_launch("tokens_gather_tiles");
 }
 

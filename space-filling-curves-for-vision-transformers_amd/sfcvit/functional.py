@@ -127,9 +127,9 @@ class _PatchEmbed2(Function):
     the persistent GEMMs at 950-1 150 TFLOP/s -- what the reference does (hilbert_embedding1D.py:36-43), minus its reshape copy."""
 
     @staticmethod
-    def forward(ctx, x, pix, w, b):
+    def forward(ctx, x, pix, w, b, desc, order):
         B, (N, P) = x.shape[0], pix.shape
-        tokens = ops.gather_tokens(_c(x), pix)
+        tokens = ops.gather_tokens(_c(x), pix, desc, order)
         ctx.save_for_backward(tokens, w)
         ctx.small = (b,)
         return ops.gemm(tokens, w, bias=b).view(B, N, w.shape[0])
@@ -139,7 +139,7 @@ class _PatchEmbed2(Function):
         tokens, w = ctx.saved_tensors
         dy2 = _c(dy).view(-1, dy.shape[-1])
         b = ctx.small[0]
-        return None, None, _wgrad(dy2, tokens, w), (_bgrad(dy2, b) if b is not None else None)
+        return None, None, _wgrad(dy2, tokens, w), (_bgrad(dy2, b) if b is not None else None), None, None
 
 
 class _PatchEmbed(Function):
@@ -182,15 +182,15 @@ def pe_two_stage(x, pix, D):
     return PE_TWO_STAGE and K % 8 == 0 and 2.0 * x.shape[0] * pix.shape[0] * K * D >= 4e9
 
 
-def patch_embed(x, pix, weight, bias, desc=None):
+def patch_embed(x, pix, weight, bias, desc=None, order=None):
     """Curve gather + patchify + projection: x [B,C,H,W] (fp32 or bf16) -> [B,N,D] bf16.
-    desc = ops.TileDesc of the pixel table (tokens are 16 x 16 tiles / 256-pixel strips) or None (only the fused kernels
-    of SFCVIT_PE_FUSED=1 use it)."""
+    desc = ops.TileDesc of the pixel table (tokens are 16 x 16 tiles / 256-pixel strips) or None: picks the tile gather
+    kernel (and the fused kernels of SFCVIT_PE_FUSED=1); order = ops.gather_order of the table on the device, or None."""
     if _traced():
         from . import library
         return library.patch_embed(x, pix, _bf(weight), _bf(bias), desc)
     if pe_two_stage(x, pix, weight.shape[0]):
-        return _PatchEmbed2.apply(x, pix, _bf(weight), _bf(bias))
+        return _PatchEmbed2.apply(x, pix, _bf(weight), _bf(bias), desc, order)
     return _PatchEmbed.apply(x, pix, _bf(weight), _bf(bias), desc)
 
 

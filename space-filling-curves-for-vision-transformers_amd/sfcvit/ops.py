@@ -533,22 +533,34 @@ def _pe_args(x, pix, n_tokens, P, D):
     return a
 
 
-_GATHER_ORDER = {}
+GATHER_TILES = _os.environ.get("SFCVIT_GATHER_TILES", "1") != "0"     # 0: the per-pixel gather kernel for tile tables too (A/B)
 
 
-def gather_tokens(x, pix):
+def gather_order(pix_host):
+    """Tokens sorted by their lowest pixel offset (numpy int32 [N]): the order in which the gather kernels pair tokens, so
+    that horizontally adjacent 16 x 16 tiles -- whose rows share 128-byte lines -- go to one workgroup.  A property of the
+    pixel table: the tokenizer computes it once, with the table (a performance hint only, see sfcvit_tokens_gather)."""
+    import numpy as np
+    return np.argsort(pix_host.min(axis=1), kind="stable").astype(np.int32)
+
+
+def gather_tokens(x, pix, desc=None, order=None):
     """x [B,C,H,W] fp32/bf16, pix [N,P] int32 (device) -> tokens [B*N, P*C (rounded up to 8)] bf16 in the reference's
-    feature order kk * C + c (sfcvit_tokens_gather): the A operand of the projection GEMM and of its weight gradient."""
+    feature order kk * C + c: the A operand of the projection GEMM and of its weight gradient.
+    desc: TileDesc of the table or None; order: device int32 [N] from gather_order() or None (tokens paired as numbered).
+    16 x 16 tiles of an fp32 image go to sfcvit_tokens_gather_tiles, everything else to sfcvit_tokens_gather."""
     N, P = pix.shape
     a = _pe_args(x, pix, N, P, 8)
     ld = (P * a.C + 7) // 8 * 8
     tokens = torch.empty((a.B * N, ld), device=x.device, dtype=_BF16)
-    key = (pix.device.index, pix.data_ptr(), pix._version, N, P)
-    order = _GATHER_ORDER.get(key)
-    if order is None:                              # once per pixel table: tokens by lowest pixel offset (neighbouring tiles pair up)
-        if len(_GATHER_ORDER) > 64:
-            _GATHER_ORDER.clear()
-        order = _GATHER_ORDER[key] = pix.min(dim=1).values.argsort().to(torch.int32).contiguous()
+    if order is not None:
+        _need(order, torch.int32, "gather order", 1)
+    if GATHER_TILES and desc is not None and desc.mode == 1 and P == 256 and a.C <= 4 and x.dtype == torch.float32:
+        origin = desc.dev[16 + N:16 + 2 * N]
+        check(_launch("tokens_gather", 0.0, lambda: lib.sfcvit_tokens_gather_tiles(_p(x), _p(pix), _p(order), _p(origin), a.B, a.C, x.shape[2],
+                                                                                 x.shape[3], N, _p(tokens), ld, _stream())),
+              "sfcvit_tokens_gather_tiles")
+        return tokens
     check(_launch("tokens_gather", 0.0, lambda: lib.sfcvit_tokens_gather(_p(x), a.x_is_bf16, _p(pix), _p(order), a.B, a.C, a.HW, N, P,
                                                                        _p(tokens), ld, _stream())), "sfcvit_tokens_gather")
     return tokens

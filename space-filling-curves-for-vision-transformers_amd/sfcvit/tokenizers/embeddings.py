@@ -45,6 +45,7 @@ class _FusedTokenizer(BasePatchEmbedding):
         self._pix = None
         self._pix_key = None
         self._desc = None
+        self._order = None
         self.proj = nn.Linear(in_channels * pre_patch * pre_patch * group, embed_dim)
 
     def _flat_table(self):          # -> 1-D integer array of length grid*grid, or None for raster
@@ -70,6 +71,9 @@ class _FusedTokenizer(BasePatchEmbedding):
             # the coalesced kernels apply (csrc/patch_embed_tiled.hip); decided once, on the host, with the table
             from .. import ops
             self._desc = ops.tile_descriptor(pix_host, img, device) if torch.device(device).type == "cuda" else None
+            # ... and the pairing order of the gather kernels (tokens by lowest pixel offset): kept with the table it
+            # belongs to, not in a cache keyed by the table's address
+            self._order = torch.from_numpy(ops.gather_order(pix_host)).to(device) if self._static_order else None
             self._pix_key = key
         return self._pix
 
@@ -96,7 +100,7 @@ class _FusedTokenizer(BasePatchEmbedding):
             pix = self._pix
         else:
             pix = self._pix_table(x.device)
-        return F.patch_embed(x, pix, self.proj.weight, self.proj.bias, self._desc)
+        return F.patch_embed(x, pix, self.proj.weight, self.proj.bias, self._desc, self._order)
 
 
 class _Curve1D(_FusedTokenizer):

@@ -848,3 +848,34 @@ def test_tokens_gather_is_the_reference_gather(ops, curve, img, P, C, B, xdt):
     assert tokens.shape == (B * N, (K + 7) // 8 * 8)
     assert torch.equal(tokens[:, :K], ref)
     assert not tokens[:, K:].any()
+
+
+@pytest.mark.parametrize("curve,img,C,B", [("hilbert", 224, 3, 3), ("z", 384, 3, 2), ("hilbert", 32, 1, 37), ("z", 64, 4, 9),
+                                           ("hilbert", 224, 3, 64), ("hilbert", 48, 2, 8), ("hilbert", 32, 3, 5), ("z", 48, 3, 7)])
+def test_tokens_gather_tiles_is_the_reference_gather(ops, curve, img, C, B):
+    """sfcvit_tokens_gather_tiles (16 x 16 tile tokens of an fp32 image: whole image lines in, curve order applied out of
+    LDS) against torch indexing with the same pixel table and against the per-pixel kernel: bit-exact; with and without
+    the order (with it and 3 channels: the strip kernel, one workgroup per row of tiles; otherwise tile pairs); batches
+    that are not a multiple of a workgroup's images; 1-4 channels; an odd number of tiles per row (48 px: 3)."""
+    from sfcvit.tokenizers.embeddings import _pixel_table
+    from sfcvit.curves import curve_table, hilbert_curve, z_curve
+    g = torch.Generator(device="cuda").manual_seed(5)
+    flat = curve_table({"hilbert": hilbert_curve, "z": z_curve}[curve], img)
+    pix_h = _pixel_table(flat, img, 1, 256)
+    desc = ops.tile_descriptor(pix_h, img, "cuda")
+    assert desc is not None and desc.mode == 1
+    pix = torch.from_numpy(pix_h).cuda()
+    order = torch.from_numpy(ops.gather_order(pix_h)).cuda()
+    x = torch.randn(B, C, img, img, device="cuda", generator=g)
+    N, K = pix.shape[0], 256 * C
+    ref = x.to(torch.bfloat16).reshape(B, C, img * img)[:, :, pix.long()].permute(0, 2, 3, 1).reshape(B * N, K)
+    assert ops.GATHER_TILES
+    for od in (order, None):
+        tokens = ops.gather_tokens(x, pix, desc, od)
+        assert tokens.shape == (B * N, K)
+        assert torch.equal(tokens, ref), (curve, img, C, B, od is None)
+    ops.GATHER_TILES = False
+    try:
+        assert torch.equal(ops.gather_tokens(x, pix, desc, order), ref)
+    finally:
+        ops.GATHER_TILES = True

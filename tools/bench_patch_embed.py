@@ -27,7 +27,8 @@ b = torch.zeros(D, device="cuda").bfloat16()
 dy = torch.randn(B, N, D, device="cuda", generator=g).bfloat16()
 
 
-tok = ops.gather_tokens(x, pix)
+order = torch.from_numpy(ops.gather_order(pix_h)).cuda()
+tok = ops.gather_tokens(x, pix, desc, order)
 dy2 = dy.view(B * N, D)
 
 
@@ -49,10 +50,11 @@ cases = {
     "fwd tiled (bf16 image)": lambda: ops.patch_embed_fwd(xb, pix, w, b, desc),
     "fwd generic (bf16 image)": lambda: ops.patch_embed_fwd(xb, pix, w, b, None),
     "fp32 -> bf16 cast of the image": lambda: x.bfloat16(),
-    "gather (fp32 image -> bf16 tokens)": lambda: ops.gather_tokens(x, pix),
+    "gather, tile kernel (fp32 image -> bf16 tokens)": lambda: ops.gather_tokens(x, pix, desc, order),
+    "gather, per-pixel kernel (fp32 image)": lambda: ops.gather_tokens(x, pix, None, order),
     "gather (bf16 image)": lambda: ops.gather_tokens(xb, pix),
     "projection GEMM on the tokens": lambda: ops.gemm(tok, w, bias=b),
-    "two-stage fwd (gather + GEMM)": lambda: ops.gemm(ops.gather_tokens(x, pix), w, bias=b),
+    "two-stage fwd (gather + GEMM)": lambda: ops.gemm(ops.gather_tokens(x, pix, desc, order), w, bias=b),
     "two-stage bwd (dW GEMM + dbias)": lambda: (ops.gemm(dy2, tok, a_kmajor=True, b_kmajor=True), ops.colsum(dy2)),
     "bwd tiled (fp32 image)": lambda: ops.patch_embed_bwd(x, pix, dy, D, True, desc),
     "bwd generic (bf16 image)": lambda: ops.patch_embed_bwd(xb, pix, dy, D, True, None),
@@ -61,6 +63,38 @@ res = {k: [] for k in cases}
 for rnd in range(3):
     for k, fn in cases.items():
         res[k].append(timeit(fn))
+# the gather as the step sees it: the image and the token buffer cold (a 1-GB fill between launches evicts L2 and the
+# 256-MB memory-side cache), one launch timed at a time
+scrub = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
+scrub.fill_(1.0)
+for label, fn in (("tile kernel", lambda: ops.gather_tokens(x, pix, desc, order)), ("per-pixel kernel", lambda: ops.gather_tokens(x, pix, None, order)),
+                  ("image cast", lambda: x.bfloat16())):
+    ts = []
+    for _ in range(7):
+        scrub.sum()                                 # caches full of CLEAN lines: nothing to write back during the launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    med = sorted(ts)[len(ts) // 2]
+    nbytes = x.numel() * 4 + tok.numel() * 2
+    print(f"gather, {label}, caches full of clean lines: {med:7.1f} us = {nbytes / med / 1e6:.2f} TB/s of {nbytes / 1e6:.0f} MB")
+for label, fn in (("tile kernel", lambda: ops.gather_tokens(x, pix, desc, order)), ("per-pixel kernel", lambda: ops.gather_tokens(x, pix, None, order)),
+                  ("image cast", lambda: x.bfloat16())):
+    ts = []
+    for _ in range(7):
+        scrub.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    med = sorted(ts)[len(ts) // 2]
+    nbytes = x.numel() * 4 + tok.numel() * 2
+    print(f"gather, {label}, caches full of dirty lines: {med:7.1f} us = {nbytes / med / 1e6:.2f} TB/s of {nbytes / 1e6:.0f} MB")
 fl = 2.0 * B * N * 768 * D
 print(f"{curve} {img}px D={D} B={B}: {fl / 1e9:.1f} GFLOP per pass, image {x.numel() * 4 / 1e6:.0f} MB fp32, tokens {B * N * D * 2 / 1e6:.0f} MB")
 for k, v in res.items():
