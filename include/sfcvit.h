@@ -166,6 +166,14 @@ typedef struct sfcvit_hier_args {
 int sfcvit_hier_tokenizer_supported(int L, int D, int C, const int32_t *P);
 /* SFCVIT_EINVAL outside that envelope or when the levels do not share the token count. */
 int sfcvit_hier_tokenizer_fwd(const sfcvit_hier_args *a, void *stream);
+/* Levels with different token counts: the reference resamples every coarser level to the first level's length with
+ * F.interpolate(mode="linear", align_corners=False) and concatenates on the feature axis
+ * (src/tokenizers/multiscale/multi_hilbert.py:33-38).  Both in one pass over bf16 level outputs:
+ *   levels[l] (device) = y_l [B, n_tokens[l], D];  out = [B, N0, L * D], N0 = n_tokens[0];  `levels` / `n_tokens` are HOST arrays.
+ * _bwd: dlevels[l] [B, n_tokens[l], D] = the transposed resampling of dout's column block l (fixed summation order). */
+int sfcvit_hier_resample_concat(const void *const *levels, const int32_t *n_tokens, int L, int B, int N0, int D, void *out, void *stream);
+int sfcvit_hier_resample_concat_bwd(const void *dout, const int32_t *n_tokens, int L, int B, int N0, int D, void *const *dlevels,
+                                    void *stream);
 
 /* ------------------------------------------------------------------------
  * bf16 MFMA GEMM with fused epilogue

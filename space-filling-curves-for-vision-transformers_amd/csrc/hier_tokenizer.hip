@@ -285,3 +285,140 @@ extern "C" int sfcvit_hier_tokenizer_fwd(const sfcvit_hier_args *a, void *stream
     else hipLaunchKernelGGL((hier_fwd_kernel<false, false>), dim3(grid), dim3(HT_THREADS), lds, s, g);
     return check_launch("hier_tokenizer_fwd");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Levels with DIFFERENT token counts (multi_hilbert.py:33-38): every coarser level is resampled to the first level's
+// length by F.interpolate(mode="linear", align_corners=False) and the levels are concatenated on the feature axis.  Both
+// in one pass: out[b, i, l D + d] = w0 y_l[b, i0, d] + w1 y_l[b, i1, d] with torch's source index
+// src = max(0, (i + 0.5) N_l / N0 - 0.5), i0 = floor(src), i1 = min(i0 + 1, N_l - 1), w1 = src - i0 (fp32, as torch's
+// upsample_linear1d computes it for bf16 input), a level of N0 tokens copied.  One thread per 8 columns of an output row.
+// Backward is the transposed gather, in a fixed order: input token j of level l collects the output rows whose taps hit
+// it (a window of ~2 N0 / N_l rows found by inverting the index map, each row's taps recomputed exactly as forward).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace sfcvit {
+namespace {
+constexpr int RS_MAXL = 8;
+struct ResampleArgs {
+    const uint16_t *lev[RS_MAXL];       // forward: y_l [B, N_l, D];  backward: unused
+    uint16_t *dlev[RS_MAXL];            // backward: d y_l
+    int n[RS_MAXL];
+    int L, B, N0, D;
+};
+
+__device__ __forceinline__ void rs_taps(int i, int nl, int n0, int &i0, int &i1, float &w1) {
+    const float scale = float(nl) / float(n0);
+    float src = scale * (float(i) + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = int(src);
+    i0 = i0 > nl - 1 ? nl - 1 : i0;
+    i1 = i0 + (i0 < nl - 1 ? 1 : 0);
+    w1 = src - float(i0);
+}
+
+__global__ __launch_bounds__(256) void hier_resample_concat_kernel(const ResampleArgs a, uint16_t *__restrict__ out) {
+    const int vpr = a.D / 8, per_row = a.L * vpr;
+    const int64_t total = int64_t(a.B) * a.N0 * per_row;
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < total; t += int64_t(gridDim.x) * 256) {
+        const int64_t row = t / per_row;
+        const int r = int(t - row * per_row), l = r / vpr, v = r - l * vpr;
+        const int b = int(row / a.N0), i = int(row - int64_t(b) * a.N0);
+        const int nl = a.n[l];
+        const uint16_t *y = a.lev[l] + size_t(b) * nl * a.D + v * 8;
+        u32x4 o;
+        if (nl == a.N0) {
+            o = *reinterpret_cast<const u32x4 *>(y + size_t(i) * a.D);
+        } else {
+            int i0, i1;
+            float w1;
+            rs_taps(i, nl, a.N0, i0, i1, w1);
+            const float w0 = 1.f - w1;
+            const u32x4 p = *reinterpret_cast<const u32x4 *>(y + size_t(i0) * a.D);
+            const u32x4 q = *reinterpret_cast<const u32x4 *>(y + size_t(i1) * a.D);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                o[k] = pack2bf(w0 * bf2f(uint16_t(p[k])) + w1 * bf2f(uint16_t(q[k])),
+                               w0 * bf2f(uint16_t(p[k] >> 16)) + w1 * bf2f(uint16_t(q[k] >> 16)));
+        }
+        *reinterpret_cast<u32x4 *>(out + size_t(row) * a.L * a.D + size_t(l) * a.D + v * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void hier_resample_concat_bwd_kernel(const ResampleArgs a, const uint16_t *__restrict__ dout, int l) {
+    const int vpr = a.D / 8, nl = a.n[l];
+    const int64_t total = int64_t(a.B) * nl * vpr;
+    const float inv = float(a.N0) / float(nl);
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < total; t += int64_t(gridDim.x) * 256) {
+        const int64_t row = t / vpr;
+        const int v = int(t - row * vpr), b = int(row / nl), j = int(row - int64_t(b) * nl);
+        const uint16_t *g = dout + (size_t(b) * a.N0) * a.L * a.D + size_t(l) * a.D + v * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto add = [&](int i, float w) {
+            const u32x4 d = *reinterpret_cast<const u32x4 *>(g + size_t(i) * a.L * a.D);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc[2 * k] += w * bf2f(uint16_t(d[k]));
+                acc[2 * k + 1] += w * bf2f(uint16_t(d[k] >> 16));
+            }
+        };
+        if (nl == a.N0) {
+            add(j, 1.f);
+        } else {
+            // rows whose source index lies in (j - 1, j + 1): src = (i + 0.5) / inv - 0.5  (two rows of slack either side)
+            int lo = int(floorf((float(j) - 0.5f) * inv - 0.5f)) - 2, hi = int(ceilf((float(j) + 1.5f) * inv - 0.5f)) + 2;
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > a.N0 - 1 ? a.N0 - 1 : hi;
+            for (int i = lo; i <= hi; i++) {
+                int i0, i1;
+                float w1;
+                rs_taps(i, nl, a.N0, i0, i1, w1);
+                if (i0 == j) add(i, 1.f - w1);
+                if (i1 == j && w1 != 0.f) add(i, w1);
+            }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = pack2bf(acc[2 * k], acc[2 * k + 1]);
+        *reinterpret_cast<u32x4 *>(a.dlev[l] + size_t(row) * a.D + v * 8) = o;
+    }
+}
+
+int rs_check(const void *const *lev, const int32_t *n_tokens, int L, int B, int N0, int D, const void *cat, const char *what) {
+    if (!lev || !n_tokens || !cat) return fail(SFCVIT_EINVAL, "%s: null pointer", what);
+    if (L < 1 || L > RS_MAXL || B <= 0 || N0 <= 0 || D <= 0 || D % 8) return fail(SFCVIT_EINVAL, "%s: L=%d B=%d N0=%d D=%d (1 <= L <= %d, D %% 8 == 0)", what, L, B, N0, D, RS_MAXL);
+    if (n_tokens[0] != N0) return fail(SFCVIT_EINVAL, "%s: the first level has %d tokens, not N0 = %d", what, n_tokens[0], N0);
+    if (!aligned16(cat)) return fail(SFCVIT_EINVAL, "%s: alignment", what);
+    for (int l = 0; l < L; l++)
+        if (!lev[l] || n_tokens[l] <= 0 || !aligned16(lev[l])) return fail(SFCVIT_EINVAL, "%s: level %d (pointer / token count / alignment)", what, l);
+    return SFCVIT_OK;
+}
+}  // namespace
+}  // namespace sfcvit
+
+extern "C" int sfcvit_hier_resample_concat(const void *const *levels, const int32_t *n_tokens, int L, int B, int N0, int D, void *out,
+                                           void *stream) {
+    if (int rc = rs_check(levels, n_tokens, L, B, N0, D, out, "hier_resample_concat")) return rc;
+    ResampleArgs a{};
+    for (int l = 0; l < L; l++) { a.lev[l] = static_cast<const uint16_t *>(levels[l]); a.n[l] = n_tokens[l]; }
+    a.L = L; a.B = B; a.N0 = N0; a.D = D;
+    const int64_t total = int64_t(B) * N0 * L * (D / 8);
+    const unsigned blocks = unsigned(std::min<int64_t>((total + 255) / 256, 1 << 16));
+    hipLaunchKernelGGL(hier_resample_concat_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, static_cast<uint16_t *>(out));
+    return check_launch("hier_resample_concat");
+}
+
+extern "C" int sfcvit_hier_resample_concat_bwd(const void *dout, const int32_t *n_tokens, int L, int B, int N0, int D, void *const *dlevels,
+                                               void *stream) {
+    if (int rc = rs_check(const_cast<const void *const *>(dlevels), n_tokens, L, B, N0, D, dout, "hier_resample_concat_bwd")) return rc;
+    ResampleArgs a{};
+    for (int l = 0; l < L; l++) { a.dlev[l] = static_cast<uint16_t *>(dlevels[l]); a.n[l] = n_tokens[l]; }
+    a.L = L; a.B = B; a.N0 = N0; a.D = D;
+    for (int l = 0; l < L; l++) {
+        const int64_t total = int64_t(B) * n_tokens[l] * (D / 8);
+        const unsigned blocks = unsigned(std::min<int64_t>((total + 255) / 256, 1 << 16));
+        hipLaunchKernelGGL(hier_resample_concat_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                           static_cast<const uint16_t *>(dout), l);
+        if (int rc = check_launch("hier_resample_concat_bwd")) return rc;
+    }
+    return SFCVIT_OK;
+}

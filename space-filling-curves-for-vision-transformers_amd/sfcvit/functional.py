@@ -194,6 +194,25 @@ def patch_embed(x, pix, weight, bias, desc=None, order=None):
     return _PatchEmbed.apply(x, pix, _bf(weight), _bf(bias), desc)
 
 
+class _ResampleConcat(Function):
+    """Linear resampling of the coarser levels to the first level's token count + concatenation (multi_hilbert.py:33-38)."""
+
+    @staticmethod
+    def forward(ctx, *levels):
+        levels = [_c(t) for t in levels]
+        ctx.n_tokens, ctx.D = [t.shape[1] for t in levels], levels[0].shape[2]
+        return ops.hier_resample_concat(levels)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return tuple(ops.hier_resample_concat_bwd(_c(dout), ctx.n_tokens, ctx.D))
+
+
+def hier_resample_concat(levels):
+    """levels: list of [B, N_l, D] -> [B, N_0, L * D] bf16 (sfcvit_hier_resample_concat)."""
+    return _ResampleConcat.apply(*[_bf(t) for t in levels])
+
+
 # SFCVIT_HIER_ONE_KERNEL=1: gather + levels + concatenation + fusion Linear in ONE kernel (csrc/hier_tokenizer.hip,
 # FUSE = true).  Default: the same kernel without its last phase (gather + levels + concatenation) followed by the
 # fusion Linear on the persistent 8-phase GEMM -- measured faster at the reference's shape (DESIGN.md 5b).

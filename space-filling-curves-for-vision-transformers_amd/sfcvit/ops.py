@@ -533,6 +533,40 @@ def _pe_args(x, pix, n_tokens, P, D):
     return a
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def hier_resample_concat(levels):
+    """levels: list of [B, N_l, D] bf16 (first = the target length) -> [B, N_0, L * D] bf16: torch's linear interpolation
+    (align_corners=False) of every other level to N_0 tokens + the concatenation, one kernel (multi_hilbert.py:33-38)."""
+    for t in levels:
+        _need(t, _BF16, "hier_resample_concat level", 3)
+    B, N0, D = levels[0].shape
+    if any(t.shape[0] != B or t.shape[2] != D for t in levels):
+        raise ValueError("hier_resample_concat: levels must share batch and width")
+    L = len(levels)
+    out = torch.empty((B, N0, L * D), device=levels[0].device, dtype=_BF16)
+    n = (ctypes.c_int32 * L)(*[t.shape[1] for t in levels])
+    check(_launch("hier_resample", 0.0, lambda: lib.sfcvit_hier_resample_concat(_ptr_array(levels), n, L, B, N0, D, _p(out), _stream())),
+          "sfcvit_hier_resample_concat")
+    return out
+
+
+def hier_resample_concat_bwd(dout, n_tokens, D):
+    """dout [B, N_0, L * D] bf16 -> list of d y_l [B, N_l, D] bf16."""
+    _need(dout, _BF16, "hier_resample_concat dout", 3)
+    B, N0, LD = dout.shape
+    L = len(n_tokens)
+    if LD != L * D or n_tokens[0] != N0:
+        raise ValueError("hier_resample_concat_bwd: shape mismatch")
+    grads = [torch.empty((B, nl, D), device=dout.device, dtype=_BF16) for nl in n_tokens]
+    n = (ctypes.c_int32 * L)(*n_tokens)
+    check(_launch("hier_resample_bwd", 0.0, lambda: lib.sfcvit_hier_resample_concat_bwd(_p(dout), n, L, B, N0, D, _ptr_array(grads), _stream())),
+          "sfcvit_hier_resample_concat_bwd")
+    return grads
+
+
 GATHER_TILES = _os.environ.get("SFCVIT_GATHER_TILES", "1") != "0"     # 0: the per-pixel gather kernel for tile tables too (A/B)
 
 

@@ -4,7 +4,7 @@ length, concatenated on the feature axis and fused by a Linear
 main.py:269-274 instantiates).  When every level has the same token count -- the reference's own configuration
 [16, 4, 1]: the resampling is then the identity -- the whole forward is ONE kernel (csrc/hier_tokenizer.hip: gather,
 level projections, concatenation in LDS, fusion GEMM).  Otherwise every level and the fusion run on their own HIP
-kernels with torch's interpolate / cat between them."""
+kernels, with the reference's linear resampling + concatenation as one more (sfcvit_hier_resample_concat)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -65,14 +65,14 @@ class _Hierarchical(nn.Module):
         return self.forward_unfused(x)
 
     def forward_unfused(self, x):
-        """Level kernels + torch interpolate / cat + fusion GEMM (any token counts)."""
+        """Level kernels, the linear resampling to the first level's token count + concatenation as one kernel
+        (sfcvit_hier_resample_concat), fusion GEMM: any token counts."""
         patches = [level(x) for level in self.levels]
-        n_tokens = self.patch_list[0]
-        for i in range(1, len(patches)):
-            if patches[i].shape[1] != n_tokens:
-                patches[i] = torch.nn.functional.interpolate(patches[i].transpose(1, 2), size=n_tokens, mode="linear",
-                                                             align_corners=False).transpose(1, 2)
-        return F.linear(torch.cat(patches, dim=-1), self.fusion.weight, self.fusion.bias)
+        widths = {p.shape[2] for p in patches}
+        if not x.is_cuda or len(widths) != 1 or next(iter(widths)) % 8:
+            raise RuntimeError("hierarchical tokenizer: the HIP path needs a CUDA (ROCm) input and level widths that are "
+                               "one multiple of 8; there is no CPU fallback")
+        return F.linear(F.hier_resample_concat(patches), self.fusion.weight, self.fusion.bias)
 
 
 class HierarchicalHilbertEmbedding(_Hierarchical):

@@ -879,3 +879,27 @@ def test_tokens_gather_tiles_is_the_reference_gather(ops, curve, img, C, B):
         assert torch.equal(ops.gather_tokens(x, pix, desc, order), ref)
     finally:
         ops.GATHER_TILES = True
+
+
+@pytest.mark.parametrize("counts,D,B", [((256, 64), 32, 2), ((64, 64, 16), 64, 3), ((64, 256), 40, 2), ((100, 36, 9, 100), 8, 5), ((7, 1), 16, 1)])
+def test_hier_resample_concat_is_torch_linear_interpolation(ops, counts, D, B):
+    """sfcvit_hier_resample_concat / _bwd against F.interpolate(mode="linear", align_corners=False) + cat on the same bf16
+    level outputs (multi_hilbert.py:33-38): forward within one bf16 step of the fp32 result (up-, down- and identity
+    resampling, non-integer ratios, a single-token level); backward (the transposed resampling, fixed order) against
+    autograd of the torch form in fp32: 1e-2 of the largest gradient (bf16 outputs)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    levels = [torch.randn(B, n, D, device="cuda", generator=g).bfloat16() for n in counts]
+    out = ops.hier_resample_concat(levels)
+    leaves = [t.float().requires_grad_(True) for t in levels]
+    parts = [leaves[0]] + [t if t.shape[1] == counts[0] else
+                           torch.nn.functional.interpolate(t.transpose(1, 2), size=counts[0], mode="linear", align_corners=False).transpose(1, 2)
+                           for t in leaves[1:]]
+    ref = torch.cat(parts, dim=-1)
+    assert out.shape == ref.shape
+    assert ((out.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-6).all()
+    dout = torch.randn(ref.shape, device="cuda", generator=g).bfloat16()
+    ref.backward(dout.float())
+    grads = ops.hier_resample_concat_bwd(dout, list(counts), D)
+    for got, leaf in zip(grads, leaves):
+        assert got.shape == leaf.shape
+        assert (got.float() - leaf.grad).abs().max() <= 1e-2 * leaf.grad.abs().max() + 1e-6

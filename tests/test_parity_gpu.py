@@ -122,7 +122,9 @@ def test_tokenizer_linearity_at_full_size():
 def test_hierarchical_tokenizer(name, golden_dir):
     """Hierarchical tokenizers against the oracle and the reference's fixture.  The last two cases are inside the fused
     kernel's envelope (csrc/hier_tokenizer.hip: one kernel for gather + level projections + concat + fusion); the
-    first two take the composed path (level kernels, torch interpolate / cat, fusion GEMM)."""
+    first two take the composed path: level kernels, sfcvit_hier_resample_concat (the reference's linear resampling +
+    concatenation, multi_hilbert.py:33-38, as one HIP kernel -- torch's interpolate / cat are made to raise here), fusion
+    GEMM."""
     from oracle.cases import HIER_CASES, HIER_FUSED_CASES
     from sfcvit.tokenizers import HierarchicalHilbertEmbedding, HierarchicalMortonEmbedding
     img, cin, plist, dim, curve, batch = HIER_CASES[name]
@@ -134,7 +136,16 @@ def test_hierarchical_tokenizer(name, golden_dir):
     ref = vit_oracle.hierarchical_tokens(x, sd, img, plist, curve)
     mod = mod.to("cuda", dtype=torch.bfloat16)
     assert mod._fusable(x.cuda()) == (name in HIER_FUSED_CASES)
-    got = mod(x.cuda()).float().cpu()
+
+    def _absent(*a, **k):
+        raise AssertionError("torch interpolate / cat on the tokenizer's forward path")
+    keep = torch.nn.functional.interpolate, torch.cat
+    torch.nn.functional.interpolate, torch.cat = _absent, _absent
+    try:
+        got = mod(x.cuda())
+    finally:
+        torch.nn.functional.interpolate, torch.cat = keep
+    got = got.float().cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max() <= 3e-2 * ref.abs().max()
     with open(os.path.join(golden_dir, "hierarchical.json")) as f:
@@ -186,6 +197,33 @@ def test_fused_hierarchical_tokenizer_matches_composed_path_and_oracle_gradients
             assert cos(g, gc) >= 0.999, (k, cos(g, gc))
             assert cos(g, go) >= 0.99, (k, cos(g, go))
             assert abs(float(g.norm() / go.norm()) - 1.0) <= 5e-2, k
+
+
+def test_resampling_hierarchical_tokenizer_gradients_against_the_oracle():
+    """hier_hilbert32_resample (256 and 64 tokens: the second level is linearly resampled 64 -> 256): gradients of
+    sum(y * r) w.r.t. every level weight / bias and the fusion Linear through sfcvit_hier_resample_concat_bwd against the
+    oracle's autograd through F.interpolate (cosine >= 0.99, norm within 5 %)."""
+    from oracle.cases import HIER_CASES
+    from sfcvit.tokenizers import HierarchicalHilbertEmbedding
+    name = "hier_hilbert32_resample"
+    img, cin, plist, dim, curve, batch = HIER_CASES[name]
+    sd = vit_oracle.hierarchical_state(img, cin, plist, dim, curve)
+    x = formula.image_batch(batch, cin, img, img)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    ref = vit_oracle.hierarchical_tokens(x, dict(sd, **leaves), img, plist, curve)
+    r = formula.wave("cotangent." + name, tuple(ref.shape))
+    (ref * r).sum().backward()
+    mod = HierarchicalHilbertEmbedding(img, cin, plist, dim)
+    mod.load_state_dict(sd)
+    mod = mod.to("cuda", dtype=torch.bfloat16)
+    y = mod(x.cuda())
+    assert (y.detach().float().cpu() - ref.detach()).abs().max() <= 3e-2 * ref.detach().abs().max()
+    (y.float() * r.cuda()).sum().backward()
+    for k, p in mod.named_parameters():
+        g, go = p.grad.detach().float().cpu().flatten(), leaves[k].grad.flatten()
+        cos = float(torch.dot(g, go) / (g.norm() * go.norm() + 1e-30))
+        assert cos >= 0.99, (k, cos)
+        assert abs(float(g.norm() / go.norm()) - 1.0) <= 5e-2, k
 
 
 def _tok_cases():
