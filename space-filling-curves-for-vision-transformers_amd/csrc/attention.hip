@@ -363,12 +363,13 @@ extern "C" int sfcvit_attention_bwd(const sfcvit_attn_args *a, void *stream) {
         if (!(env && env[0] == '0')) {
             sfcvit_attn_args f = *a;
             if (!a->colsum_out) f.colsum_part = nullptr;
-            // The column sums of dK and dV leave the kernel as 128 floats per workgroup (its key waves hold whole columns).
-            // Those of dQ are cheaper from a pass over the Q third of the dqkv just written (77 MB at ViT-B / 256: 16 us) than
-            // from the two dQ waves, whose per-chunk lane reductions + LDS read-modify-writes made them the slowest waves of a
-            // chunk (+37 us per launch, measured: 289.5 vs 252.8 us).  SFCVIT_ATTN_DQSUM=kernel restores the in-kernel sums (A/B).
+            // The column sums of dK and dV leave the kernel as 128 floats per item (its key waves hold whole columns).  Those of
+            // dQ come from the key waves as well since round 4: sum_q dQ[q, :] = scale sum_k (sum_q dS[q, k]) K[k, :], one add
+            // per score in the loop and a 16 x 64 product per wave after it.  (Round 3 took them from the two dQ waves -- per-chunk
+            // lane reductions + LDS read-modify-writes on the waves a step waits for, +37 us per launch -- and therefore
+            // defaulted to a separate 16-us pass over the Q third of dqkv, which SFCVIT_ATTN_DQSUM=pass still selects: A/B.)
             const char *dq = getenv("SFCVIT_ATTN_DQSUM");
-            const int dq_in_kernel = dq && dq[0] == 'k';
+            const int dq_in_kernel = !(dq && dq[0] == 'p');
             if (int rc = attn_seq_bwd_fused(f, dq_in_kernel, s); rc >= 0) {
                 if (rc || !a->colsum_out) return rc;
                 if (dq_in_kernel) return launch_colsum_reduce(a->colsum_part, a->B, D3, a->colsum_out, a->colsum_bf16, stream);

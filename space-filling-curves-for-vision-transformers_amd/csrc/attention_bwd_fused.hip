@@ -43,8 +43,9 @@ using namespace attn;
 
 constexpr int FT = 1024, FWAVES = 16, FMAXC = 7;   // threads, waves, 32-row chunks (N <= 224)
 constexpr int FUSED_ROW_BYTES = 4 * 128 + 2 * 64 + 6 * 4;    // LDS bytes per padded sequence row: Q, dO, two K images; dS exchange x 2; two sets of lse / delta / row key
+constexpr int FUSED_CS_BYTES = 16 * 128 * 4;                   // column-sum staging [FWAVES][dK | dV][64] floats
 constexpr int FUSED_POST_BYTES = 8192;                       // own scratch: the [32][64] partial dK / dV of a shared fragment (+ as much again for short sequences, whose K image is too small for the column-sum staging)
-constexpr int FUSED_EXTRA = 256 + 64;                        // + 64 column sums of dQ + two item records (3 pointers each, 8-byte slots)
+constexpr int FUSED_EXTRA = 256 + 64 + 14 * 64 * 4;          // (256 spare) + two item records (3 pointers each, 8-byte slots) + the key waves' shares of the dQ column sums [14][64]
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -88,12 +89,12 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     stagger_start(stag_round, stag_per, stag_ticks);
     char *qimg = smem, *doimg = smem + npad * 128, *kimg0 = smem + 2 * npad * 128, *dsb = smem + 4 * npad * 128;
     char *small0 = dsb + 2 * npad * 64;                               // two sets of [lse | delta | row key], npad words each
-    float *qcs = reinterpret_cast<float *>(smem + npad * FUSED_ROW_BYTES);   // [64]
     // Item records: the global pointers a step needs (where the NEXT item's Q / K and dO rows come from, where the CURRENT item's
     // dQ goes), written once per item by thread 0 and read from LDS where they are used.  Formed from the item number in
     // scalar registers they cost every one of the 16 waves ~60 scalar instructions per step (an integer division among them)
     // and, kept across the loop, the scalar registers the kernel does not have (106 used, 48 spilled).
     unsigned long long *rec0 = reinterpret_cast<unsigned long long *>(smem + npad * FUSED_ROW_BYTES + 256);   // [2][4]
+    float *qpart = reinterpret_cast<float *>(smem + npad * FUSED_ROW_BYTES + 256 + 64);                          // [14 key-side waves][64]
     char *own_scratch = smem + npad * FUSED_ROW_BYTES + FUSED_EXTRA;         // short sequences: a K image is smaller than the scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.N, D = a.H * HD, ld = 3 * D;
@@ -190,7 +191,6 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         dma_rows(qimg, base, ld, N, npad, tid);
         dma_rows(doimg, static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD, D, N, npad, tid);
         dma_rows(kimg0, base + D, ld, N, npad, tid);
-        if (tid < 64) qcs[tid] = 0.f;
         {   // exchange rows no key wave writes (keys 16 nf .. npad - 1), both halves of the double buffer; written once
             const int nz = (npad - 16 * nf) * 4;         // 16-byte pieces per half
             for (int i = tid; i < 2 * nz; i += FT) {
@@ -218,6 +218,11 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int hf = 0; hf < 4; hf++) dk[hf] = dv[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // sum over the queries of dS[q, key] for this lane's key (its 4 query rows of every fragment): the column sums of dQ are
+    // sum_q dQ[q, :] = scale sum_k (sum_q dS[q, k]) K[k, :] -- one multiply-add per score here and a 16 x 64 product per key
+    // wave after the loop, instead of 8 cross-lane reductions + 8 LDS read-modify-writes per step on the two dQ waves, which
+    // the step waits for (263 -> 2xx us with the in_proj bias gradient, profiles/r4/attention_bench_r4.txt)
+    float ksum = 0.f;
 
     // one step of a key wave: S^T, dP^T of its keys against the 32 queries of chunk c, P and dS, dV += P^T dO, dK += dS^T Q,
     // and its [16 keys][32 queries] block of dS^T into the exchange image
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
                 for (int r = 0; r < 4; r++)
                     if (key >= N) dr[r] = 0.f;
             }
+            ksum += (dr[0] + dr[1]) + (dr[2] + dr[3]);
             pp[t] = u32x2{pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3])};
             dd[t] = u32x2{pack2bf(dr[0], dr[1]), pack2bf(dr[2], dr[3])};
         }
@@ -314,17 +320,6 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
             }
         }
         mfma_fence();
-        if (a.colsum_part && dq_sums) {
-            // column sums of this chunk's dQ tiles, accumulated in this wave's 32 LDS words (one writer per word, chunk
-            // after chunk: a fixed order; registers for running sums are not to be had).  Padded queries have dS = 0.
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float sq = row16_sum(acc[hh][0][r] + acc[hh][1][r]);
-                    if (li == 0) qcs[32 * dqw + 16 * hh + 4 * g + r] += sq;
-                }
-        }
         // acc[hh][qf][r] = dQ[query 32 (c-1) + 16 qf + li][head column 32 dqw + 16 hh + 4 g + r]
         // one 16-byte store per lane and query fragment (the pieces of hh = 0 / 1 exchanged as in store_rows): 16 rows x 64 bytes
 #pragma unroll
@@ -376,6 +371,31 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     if (is_dq) dq_step(nc);                           // (before the fetch: a dQ wave's stores are then the OLDEST operations in its queue)
     if (has_next) fetch_item(nxt, small_next);
     ATRACE(tr_i + 8);
+    if (a.colsum_part && dq_sums && is_key) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int g = ln >> 4, li = ln & 15, key = 16 * kfi + li;
+        float sk = ksum;                                                  // lanes li, li + 16, li + 32, li + 48 hold the 4 quarters of key li
+        {
+            const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(sk), __float_as_uint(sk), false, false);
+            sk = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+            const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(sk), __float_as_uint(sk), false, false);
+            sk = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+        }
+        if (key >= N) sk = 0.f;                                           // (rows of the K image past N repeat row N - 1)
+#pragma unroll
+        for (int hc = 0; hc < 2; hc++) {
+            const u32x4 kv = *reinterpret_cast<const u32x4 *>(kimg + kc_off(key, 2 * g + hc));
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float q0 = row16_sum(sk * bf2f(uint16_t(kv[e]))), q1 = row16_sum(sk * bf2f(uint16_t(kv[e] >> 16)));
+                if (li == 0) {                                            // this fragment's share, columns 16 g + 8 hc + 2 e (+ 1); read after two barriers
+                    qpart[wave * 64 + 16 * g + 8 * hc + 2 * e] = q0 * scale;
+                    qpart[wave * 64 + 16 * g + 8 * hc + 2 * e + 1] = q1 * scale;
+                }
+            }
+        }
+    }
     float *px = reinterpret_cast<float *>(own_scratch);               // [32][64] lane-private words: partial dK / dV of a shared fragment
     if (split && wave == nf) {                        // the shared fragment: wave nf hands its partial dK / dV to wave nf - 1
         mfma_fence();
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         // (DPP reduction), the 13 key waves / 2 dQ waves meet in LDS (the exchange image is free now) and are summed in
         // a fixed order: bit-reproducible.  Layout of the partials: [batch][q | k | v thirds of 3 D], summed over
         // the batch afterwards (launch_colsum_reduce).
-        float *cs = reinterpret_cast<float *>(npad * 128 >= 8192 ? kimg : own_scratch + 8192);   // [FWAVES][128]: the item's K image is dead by now
+        float *cs = reinterpret_cast<float *>(npad * 128 >= FUSED_CS_BYTES ? kimg : own_scratch + FUSED_POST_BYTES);   // [FWAVES][128]: the item's K image is dead by now
         if (owns) {
 #pragma unroll
             for (int hf = 0; hf < 4; hf++)
@@ -435,10 +455,13 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         if (tid < 192) {
             const int third = tid >> 6, c = tid & 63;
             float s = 0.f;
-            if (third == 0) s = qcs[c] * scale;
-            else
+            if (third == 0) {
+                if (dq_sums)
+                    for (int w = 0; w < nf + (split ? 1 : 0); w++) s += qpart[w * 64 + c];
+            } else {
                 for (int w = 0; w < nf; w++) s += cs[w * 128 + (third - 1) * 64 + c];
-            a.colsum_part[size_t(b) * 3 * D + third * D + h * HD + c] = s;
+            }
+            if (third || dq_sums) a.colsum_part[size_t(b) * 3 * D + third * D + h * HD + c] = s;
         }
     }
     ATRACE(tr_i + 10);
@@ -447,9 +470,8 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
 #ifdef SFCVIT_ATTN_TRACE
     if (blockIdx.x == 5 && (threadIdx.x & 63) == 0 && tr_i == 16) g_attn_trace[256 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();
 #endif
-    __syncthreads();                                  // scratch and qcs have been read
+    __syncthreads();                                  // scratch has been read
     ATRACE(tr_i + 12);
-    if (tid < 64) qcs[tid] = 0.f;
     delta_item(small_next);
     ATRACE(tr_i + 13);
     __syncthreads();
@@ -476,7 +498,7 @@ int attn_seq_bwd_fused(const sfcvit_attn_args &a, int dq_sums, hipStream_t s) {
     if (a.hd != HD || a.N > FUSED_MAX_N) return -1;
     const int npad = (a.N + 31) / 32 * 32;
     const bool nf13 = (a.N + 15) / 16 == 13, drop = a.dropout_p > 0.f;
-    const size_t lds = size_t(npad) * FUSED_ROW_BYTES + FUSED_EXTRA + FUSED_POST_BYTES + (npad * 128 >= 8192 ? 0 : 8192);
+    const size_t lds = size_t(npad) * FUSED_ROW_BYTES + FUSED_EXTRA + FUSED_POST_BYTES + (npad * 128 >= FUSED_CS_BYTES ? 0 : FUSED_CS_BYTES);
     // One workgroup per CU walking the (batch, head) items with the next one staged behind the current (kernel header);
     // SFCVIT_ATTN_BWD_PERSIST=0: one workgroup per item, i.e. the kernel of rounds 2-3 (A/B).
     const int items = a.B * a.H, cus = device_cu_count();
@@ -485,7 +507,9 @@ int attn_seq_bwd_fused(const sfcvit_attn_args &a, int dq_sums, hipStream_t s) {
     // Start-up stagger (attention_common.h): every workgroup opens with a 117 KiB load burst and they all take the same time,
     // so launched together they stay in lockstep.  Two slots 4.5 us apart: 270.8 -> 257.1 us at ViT-B / 256 with one workgroup
     // per item (3 or 4 slots, 2-8 us: 255.6-258.6).  SFCVIT_ATTN_STAGGER_BWD = "slots,ticks" (10 ns) overrides; "1,0" = off.
-    int slots = 2, ticks = 450;
+    // The persistent form (round 4) pays the burst once per 12 items and its workgroups drift apart on their own: the stagger
+    // costs it 5 us (227.6 vs 222.7 us, profiles/r4/attention_bench_r4.txt), so it is on for one-workgroup-per-item launches only.
+    int slots = grid < items ? 1 : 2, ticks = 450;
     if (const char *e = getenv("SFCVIT_ATTN_STAGGER_BWD")) sscanf(e, "%d,%d", &slots, &ticks);
     if (slots < 1) slots = 1;
     const int round = 256, per = (round + slots - 1) / slots;

@@ -37,7 +37,8 @@ byt_f = B * N * 4 * H * 64 * 2
 byt_b = B * N * 8 * H * 64 * 2
 csum = torch.empty(3 * H * 64, device="cuda", dtype=torch.bfloat16)
 rows = {"fwd": [], "fwd tiled (SFCVIT_ATTN_LONG=0)": [], "bwd fused": [], "bwd fused + in_proj bias column sums (as in the training step)": [],
-        "bwd fused, no start-up stagger": [], "bwd fused, one workgroup per item (SFCVIT_ATTN_BWD_PERSIST=0)": [], "bwd two-kernel": [], "bwd two-kernel, tiled (SFCVIT_ATTN_LONG=0)": []}
+        "bwd fused + column sums, dQ's from a separate pass (SFCVIT_ATTN_DQSUM=pass, round 3)": [],
+        "bwd fused, two-slot start-up stagger (SFCVIT_ATTN_STAGGER_BWD=2,450)": [], "bwd fused, one workgroup per item (SFCVIT_ATTN_BWD_PERSIST=0)": [], "bwd two-kernel": [], "bwd two-kernel, tiled (SFCVIT_ATTN_LONG=0)": []}
 for rnd in range(5):
     rows["fwd"].append(timeit(lambda: ops.attention_fwd(qkv, H, p, 5)))
     os.environ["SFCVIT_ATTN_LONG"] = "0"
@@ -46,8 +47,11 @@ for rnd in range(5):
     os.environ["SFCVIT_ATTN_BWD_FUSED"] = "1"
     rows["bwd fused"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
     rows["bwd fused + in_proj bias column sums (as in the training step)"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5, colsum=csum)))
-    os.environ["SFCVIT_ATTN_STAGGER_BWD"] = "1,0"
-    rows["bwd fused, no start-up stagger"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
+    os.environ["SFCVIT_ATTN_DQSUM"] = "pass"
+    rows["bwd fused + column sums, dQ's from a separate pass (SFCVIT_ATTN_DQSUM=pass, round 3)"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5, colsum=csum)))
+    del os.environ["SFCVIT_ATTN_DQSUM"]
+    os.environ["SFCVIT_ATTN_STAGGER_BWD"] = "2,450"
+    rows["bwd fused, two-slot start-up stagger (SFCVIT_ATTN_STAGGER_BWD=2,450)"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
     del os.environ["SFCVIT_ATTN_STAGGER_BWD"]
     os.environ["SFCVIT_ATTN_BWD_PERSIST"] = "0"
     rows["bwd fused, one workgroup per item (SFCVIT_ATTN_BWD_PERSIST=0)"].append(timeit(lambda: ops.attention_bwd(qkv, out, lse, dout, H, p, 5)))
@@ -63,5 +67,5 @@ for k, v in rows.items():
     v = sorted(v)
     med = v[len(v) // 2]
     f, by = (fl, byt_f) if k.startswith("fwd") else (2.5 * fl, byt_b)
-    print(f"{k:68s} median {med:7.1f} us  min {v[0]:7.1f}   {f / med / 1e6:7.1f} TFLOP/s   {by / med / 1e3:7.1f} GB/s algorithmic "
+    print(f"{k:86s} median {med:7.1f} us  min {v[0]:7.1f}   {f / med / 1e6:7.1f} TFLOP/s   {by / med / 1e3:7.1f} GB/s algorithmic "
           f"({by / med / 1e3 / 8000 * 100:4.1f} % of 8 TB/s)")
