@@ -47,6 +47,13 @@ constexpr int FUSED_CS_BYTES = 16 * 128 * 4;                   // column-sum sta
 constexpr int FUSED_POST_BYTES = 8192;                       // own scratch: the [32][64] partial dK / dV of a shared fragment (+ as much again for short sequences, whose K image is too small for the column-sum staging)
 constexpr int FUSED_EXTRA = 256 + 64 + 14 * 64 * 4;          // (256 spare) + two item records (3 pointers each, 8-byte slots) + the key waves' shares of the dQ column sums [14][64]
 
+// tools/attn_isa_budget.py compiles this file with -DSFCVIT_ISA_MARKERS and buckets the instructions between the marks
+#ifdef SFCVIT_ISA_MARKERS
+#define ISA_MARK(name) asm volatile("; ISA_MARK " name ::: "memory")
+#else
+#define ISA_MARK(name) do { } while (0)
+#endif
+
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 #ifdef SFCVIT_ATTN_TRACE
@@ -357,8 +364,15 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     ATRACE(tr_i);
     for (int c = 0; c < nc; c++) {
         if (has_next && c >= 1) prefetch(c);
-        if (is_key) key_step(c);
-        else if (is_dq && c >= 1) dq_step(c);
+        if (is_key) {
+            ISA_MARK("key_step begin");
+            key_step(c);
+            ISA_MARK("key_step end");
+        } else if (is_dq && c >= 1) {
+            ISA_MARK("dq_step begin");
+            dq_step(c);
+            ISA_MARK("dq_step end");
+        }
         if (!is_dq) dma_wait();                       // this step's DMA has landed (a key wave has no other vector-memory operation in flight)
         __syncthreads();
         ATRACE(tr_i + 1 + c);
