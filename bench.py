@@ -368,6 +368,10 @@ def main():
             if "tokens_gather" in kern:     # two-stage patch embed: the gather alone (HBM-bound: image in, bf16 tokens out); its
                 # projection and weight gradient are ordinary launches of the GEMM families above
                 detail["tokens_gather"] = frac_entry(kern["tokens_gather"], bound_flops=False, bytes_per_launch=pe_in + bh * 3 * patch * 2)
+                gsym = [k for k in traffic if k.startswith("tokens_gather")]      # PMC bytes per launch of the gather kernel that ran
+                if len(gsym) == 1 and traffic[gsym[0]].get("traffic_bytes") is not None:
+                    detail["tokens_gather"]["traffic"] = traffic[gsym[0]]["traffic_bytes"]
+                    detail["tokens_gather"]["rocprof_symbol"] = gsym[0]
             detail["step"] = {"tflops": out["step_tflops_per_gpu"], "mfma_frac": out["step_mfma_frac"]}
             out["roofline_detail"] = detail
             out["kernel_timing"] = (f"HIP events around every launch of the GEMMs / attention / patch embed in {tsteps} of the "

@@ -65,12 +65,13 @@ __device__ unsigned long long g_attn_trace[512];
 
 // Stage npad rows x 64 cols (128-B rows) into a kc image by LDS-DMA; the bank swizzle goes on the SOURCE chunk
 // (the DMA writes lane-linear); rows >= N copy row N - 1.
-__device__ __forceinline__ void dma_rows(char *img, const uint16_t *__restrict__ src, int ld, int N, int npad, int tid) {
+__device__ __forceinline__ void dma_rows(char *img, const uint16_t *__restrict__ src, int ld, int N, int npad, int tid, int nt = 0) {
     for (int p = tid; p < npad * 8; p += FT) {
         const int row = p >> 3, cs = p & 7;
         const int c = cs ^ kc_swz(row);
         const uint16_t *g = src + size_t(min(row, N - 1)) * ld + c * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(img + p * 16), 16, 0, 0);
+        if (nt) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(img + p * 16), 16, 0, 2);      // nt: read once, do not allocate
+        else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(img + p * 16), 16, 0, 0);
     }
 }
 
@@ -90,7 +91,7 @@ __device__ __forceinline__ bf16x8 ds_tr_frag(const char *slot, int key0, int lan
 // NFC: number of 16-row fragments at compile time (0 = from N); DROP: dropout on the probabilities (compile-time: a
 // runtime flag put a branch around every hash, each one a scheduling barrier between the MFMAs).
 template <int NFC, bool DROP>
-__global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_attn_args a, int npad, int stag_round, int stag_per, int stag_ticks, int dq_sums, int items) {
+__global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_attn_args a, int npad, int stag_round, int stag_per, int stag_ticks, int dq_sums, int items, int nt) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stagger_start(stag_round, stag_per, stag_ticks);
@@ -137,7 +138,10 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         for (int i = 0; i < 2; i++) {
             const int p = tid + FT * i, row = p >> 3, c = (p & 7) ^ kc_swz(row);
             opiece[i] = u32x4{0u, 0u, 0u, 0u};
-            if (row < N) opiece[i] = *reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(a.out) + (size_t(b) * N + row) * D + h * HD + c * 8);
+            if (row < N) {
+                const u32x4 *op = reinterpret_cast<const u32x4 *>(static_cast<const uint16_t *>(a.out) + (size_t(b) * N + row) * D + h * HD + c * 8);
+                opiece[i] = nt ? __builtin_nontemporal_load(op) : *op;
+            }
         }
         const float *lse = a.lse + (size_t(b) * a.H + h) * N;
         float *lse_w = reinterpret_cast<float *>(small);
@@ -179,7 +183,8 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         const int c = cs ^ kc_swz(row);
         const uint16_t *gp = src + size_t(min(row, N - 1)) * sld + c * 8;
         const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base + uint32_t(img - smem) + uint32_t(p) * 16u);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
+        if (nt) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gp), "s"(m0v) : "memory");
+        else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory");
     };
     auto dma_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
@@ -195,9 +200,9 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
         fetch_item(item, small0);
         if (tid == 0) write_record(item, rec0);
-        dma_rows(qimg, base, ld, N, npad, tid);
-        dma_rows(doimg, static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD, D, N, npad, tid);
-        dma_rows(kimg0, base + D, ld, N, npad, tid);
+        dma_rows(qimg, base, ld, N, npad, tid, nt);
+        dma_rows(doimg, static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD, D, N, npad, tid, nt);
+        dma_rows(kimg0, base + D, ld, N, npad, tid, nt);
         {   // exchange rows no key wave writes (keys 16 nf .. npad - 1), both halves of the double buffer; written once
             const int nz = (npad - 16 * nf) * 4;         // 16-byte pieces per half
             for (int i = tid; i < 2 * nz; i += FT) {
@@ -500,8 +505,9 @@ constexpr int FUSED_MAX_LDS = FUSED_MAX_N * FUSED_ROW_BYTES + FUSED_EXTRA + FUSE
 
 template <int NFC, bool DROP>
 int launch_fused(const sfcvit_attn_args &a, int npad, size_t lds, int grid, int round, int per, int ticks, int dq_sums, hipStream_t s) {
+    static const int nt = [] { const char *e = getenv("SFCVIT_ATTN_NT"); return e ? atoi(e) : 0; }();
     if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<NFC, DROP>), FUSED_MAX_LDS, "attention_bwd_fused attribute")) return rc;
-    hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<NFC, DROP>), dim3(grid), dim3(FT), lds, s, a, npad, round, per, ticks, dq_sums, a.B * a.H);
+    hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<NFC, DROP>), dim3(grid), dim3(FT), lds, s, a, npad, round, per, ticks, dq_sums, a.B * a.H, nt & 1);
     return check_launch("attention_bwd_fused");
 }
 
