@@ -254,7 +254,9 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const int qf = 2 * c + t;
-            if (tsel == 1 - t) {                                  // the other wave of a shared fragment does this one
+            // the other wave of a shared fragment does this one -- or the fragment has no query at all (N = 196: rows
+            // 208 .. 223 of the last chunk; 1 / 14 of the loop's score work)
+            if (tsel == 1 - t || 16 * qf >= N) {
                 pp[t] = dd[t] = u32x2{0u, 0u};
                 continue;
             }
@@ -319,15 +321,27 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         f32x4 acc[2][2];                                         // [head-column fragment hh][query fragment qf]
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (32 * (c - 1) + 16 < N) {
 #pragma unroll
-        for (int ks = 0; ks < FMAXC; ks++) {
-            if (ks < nc) {                                       // key steps of 32 (keys are padded like the queries)
-                const bf16x8 b0 = ds_tr_frag(slot, 32 * ks, ds_r), b1 = ds_tr_frag(slot, 32 * ks, ds_r ^ 32);
+            for (int ks = 0; ks < FMAXC; ks++) {
+                if (ks < nc) {                                   // key steps of 32 (keys are padded like the queries)
+                    const bf16x8 b0 = ds_tr_frag(slot, 32 * ks, ds_r), b1 = ds_tr_frag(slot, 32 * ks, ds_r ^ 32);
 #pragma unroll
-                for (int hh = 0; hh < 2; hh++) {
-                    const bf16x8 kt = tr_frag_at(kimg, 32 * ks, kt_off[hh]);
-                    acc[hh][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, b0, acc[hh][0], 0, 0, 0);
-                    acc[hh][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, b1, acc[hh][1], 0, 0, 0);
+                    for (int hh = 0; hh < 2; hh++) {
+                        const bf16x8 kt = tr_frag_at(kimg, 32 * ks, kt_off[hh]);
+                        acc[hh][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, b0, acc[hh][0], 0, 0, 0);
+                        acc[hh][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, b1, acc[hh][1], 0, 0, 0);
+                    }
+                }
+            }
+        } else {                                                 // the chunk's second query fragment is past N (N = 196: the last chunk): half the step
+#pragma unroll
+            for (int ks = 0; ks < FMAXC; ks++) {
+                if (ks < nc) {
+                    const bf16x8 b0 = ds_tr_frag(slot, 32 * ks, ds_r);
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++)
+                        acc[hh][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_at(kimg, 32 * ks, kt_off[hh]), b0, acc[hh][0], 0, 0, 0);
                 }
             }
         }
