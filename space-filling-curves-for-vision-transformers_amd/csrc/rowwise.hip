@@ -83,6 +83,74 @@ __global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const uint16_t *__restr
     }
 }
 
+// Two rows per wave (D = 768: 2 x 96 vectors = 3 per lane exactly, where one row leaves a third of the lanes idle on the second
+// load; D = 1 024: 4 per lane): twice the bytes in flight per wave -- at one 1.5-KB row per wave a CU holds 48 KB of loads, about
+// what 6 TB/s needs at this latency, and the kernel ran at 4.6 -- and the two rows' reductions overlap.  In the step (rocprofv3,
+// same box, alternating): 33.4 -> 30.8-31.2 us per launch; alone both forms take 26.9 us (inputs warm in the memory-side cache).
+// Nontemporal loads of x on top: 31.4-31.5 us, not kept.
+template <int VPL>
+__global__ __launch_bounds__(THREADS) void ln_fwd2_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ gamma,
+                                                          const uint16_t *__restrict__ beta, uint16_t *__restrict__ y,
+                                                          float *__restrict__ mean, float *__restrict__ rstd, int M,
+                                                          int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = 2 * (blockIdx.x * WAVES + (threadIdx.x >> 6));
+    if (row0 >= M) return;
+    const int nvec = D >> 3;                                   // 2 * nvec <= 64 * VPL (host)
+    const bool two = row0 + 1 < M;
+    float v[VPL][8];
+    int col[VPL];                                              // vector column, or -1; bit 30: second row
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int c = lane + 64 * i, r = c >= nvec ? 1 : 0, cc = c - r * nvec;
+        col[i] = (c < 2 * nvec && (r == 0 || two)) ? (cc | (r << 30)) : -1;
+        if (col[i] >= 0) {
+            unpack8(*reinterpret_cast<const u32x4 *>(x + size_t(row0 + r) * D + cc * 8), v[i]);
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) t += v[i][j];
+            if (r) s1 += t; else s0 += t;
+        }
+    }
+    const float mu0 = wave_sum(s0) / float(D), mu1 = wave_sum(s1) / float(D);
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; i++)
+        if (col[i] >= 0) {
+            const bool r = col[i] >> 30;
+            const float mu = r ? mu1 : mu0;
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float d = v[i][j] - mu;
+                t += d * d;
+            }
+            if (r) q1 += t; else q0 += t;
+        }
+    const float rs0 = rsqrtf(wave_sum(q0) / float(D) + eps), rs1 = rsqrtf(wave_sum(q1) / float(D) + eps);
+    if (lane == 0) {
+        mean[row0] = mu0;
+        rstd[row0] = rs0;
+        if (two) {
+            mean[row0 + 1] = mu1;
+            rstd[row0 + 1] = rs1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; i++)
+        if (col[i] >= 0) {
+            const int r = col[i] >> 30, cc = col[i] & 0xFFFFFF;
+            const float mu = r ? mu1 : mu0, rs = r ? rs1 : rs0;
+            float g[8], b[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4 *>(gamma + cc * 8), g);
+            unpack8(*reinterpret_cast<const u32x4 *>(beta + cc * 8), b);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+            *reinterpret_cast<u32x4 *>(y + size_t(row0 + r) * D + cc * 8) = pack8(o);
+        }
+}
+
 // ---------------------------------------------------------------------------
 // LayerNorm backward.  Each wave walks rows with a grid stride, keeps its lanes'
 // columns of dgamma / dbeta in registers, and the block writes one partial row
@@ -790,6 +858,13 @@ extern "C" int sfcvit_layernorm_fwd(const void *x, const void *gamma, const void
     const auto *gp = static_cast<const uint16_t *>(gamma);
     const auto *bp = static_cast<const uint16_t *>(beta);
     auto *yp = static_cast<uint16_t *>(y);
+    static const int two_rows = [] { const char *e = getenv("SFCVIT_LN_FWD_TWO_ROWS"); return e ? atoi(e) : 1; }();
+    if (two_rows && (D == 768 || D == 1024) && M >= 4096) {
+        const dim3 grid2((M + 2 * WAVES - 1) / (2 * WAVES));
+        if (D == 768) hipLaunchKernelGGL(ln_fwd2_kernel<3>, grid2, block, 0, s, xp, gp, bp, yp, mean, rstd, M, D, eps);
+        else hipLaunchKernelGGL(ln_fwd2_kernel<4>, grid2, block, 0, s, xp, gp, bp, yp, mean, rstd, M, D, eps);
+        return check_launch("layernorm_fwd");
+    }
     if (D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, xp, gp, bp, yp, mean, rstd, M, D, eps);
     else if (D <= 1024) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, xp, gp, bp, yp, mean, rstd, M, D, eps);
     else if (D <= 2048) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, xp, gp, bp, yp, mean, rstd, M, D, eps);

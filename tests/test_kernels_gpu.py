@@ -144,6 +144,25 @@ def test_gemm_rejects_bad_arguments(ops):
         ops.gemm(a.cpu(), a.cpu())              # no CPU fallback
 
 
+@pytest.mark.parametrize("M,D", [(4097, 768), (12544, 768), (4099, 1024)])
+def test_layernorm_forward_two_rows_per_wave_is_the_one_row_kernel(ops, M, D):
+    """From 4 096 rows on, D = 768 / 1 024 run the forward with two rows per wave (ln_fwd2_kernel): bit-identical output,
+    mean and rstd to the one-row kernel -- same per-row arithmetic in the same order up to the lane a vector sits in --
+    within one bf16 step at most where the wave sums associate differently; odd M (a last wave with one row)."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = bf(torch.randn(M, D, device="cuda", generator=g) * 2 + 0.5)
+    gamma = bf(1 + 0.2 * torch.randn(D, device="cuda", generator=g))
+    beta = bf(0.1 * torch.randn(D, device="cuda", generator=g))
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    y1, mean1, rstd1 = (torch.cat(t) for t in zip(*(ops.layernorm_fwd(x[i:i + 1024].contiguous(), gamma, beta) for i in range(0, M, 1024))))
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), gamma.float(), beta.float(), 1e-5)
+    close(y, ref)
+    assert torch.allclose(mean, mean1, rtol=0, atol=1e-5) and torch.allclose(rstd, rstd1, rtol=1e-5, atol=0)
+    d = (y.float() - y1.float()).abs()
+    assert (d <= 2.0 ** -7 * y1.float().abs() + 1e-6).all()
+    assert float((d > 0).float().mean()) <= 1e-3
+
+
 @pytest.mark.parametrize("M,D", [(7, 192), (1000, 768), (513, 1024), (64, 128)])
 def test_layernorm(ops, M, D):
     g = torch.Generator(device="cuda").manual_seed(4)
