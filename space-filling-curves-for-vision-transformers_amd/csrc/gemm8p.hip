@@ -202,7 +202,7 @@ __device__ __forceinline__ void store_row_pair(const sfcvit_gemm_args &g, int m,
 
 // P2 = the two-phase schedule of a k-tile (see ktile2 below): 4 barriers per k-tile instead of 8.
 template <int NI, int MASK, bool P2 = false>
-__global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, unsigned *__restrict__ counters, int stag_slots, int stag_ticks) {
+__global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, unsigned *__restrict__ counters, int stag_slots, int stag_ticks, int walk) {
     constexpr int BM = 32 * NI, GR = 16 * NI;               // tile rows, rows per wave group
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE array: ring of 2 x [A0 | A1 | B0 | B1]
     if (stag_ticks > 0) {   // start-up stagger (see launch()): the workgroups of an XCD start in `slots` groups, `ticks` x 10 ns apart
@@ -230,7 +230,16 @@ __global__ __launch_bounds__(T) void gemm8p_kernel(const sfcvit_gemm_args g, uns
         const long t = long(l / unsigned(per_xcd)) * G + xcd * per_xcd + int(l % unsigned(per_xcd));
         // published as (row tile << 16) | column tile: the divisions by NT are done here, by thread 0 off the critical
         // path, not by every wave when its staging cursor crosses into the tile (measured: ~1000 clocks per tile)
-        return t < ntiles ? int((unsigned(t) / unsigned(NT)) << 16 | (unsigned(t) % unsigned(NT))) : -1;
+        if (t >= ntiles) return -1;
+        if (walk > 0 && walk < NT) {
+            // column windows of `walk` tiles: the 32 tiles an XCD works on at a time are then ~32 / walk row tiles x walk column
+            // tiles instead of 32 / NT x NT -- fewer distinct operand panels per chunk (SFCVIT_GEMM_WALK, A/B)
+            const unsigned MT = unsigned(ntiles / NT), full = unsigned(NT / walk) * MT * unsigned(walk), ut = unsigned(t);
+            const unsigned wcur = ut < full ? unsigned(walk) : unsigned(NT % walk), base = ut < full ? (ut / (MT * walk)) * walk : unsigned(NT / walk) * walk;
+            const unsigned tt = ut < full ? ut % (MT * walk) : ut - full;
+            return int((tt / wcur) << 16 | (base + tt % wcur));
+        }
+        return int((unsigned(t) / unsigned(NT)) << 16 | (unsigned(t) % unsigned(NT)));
     };
     auto finish = [&]() __attribute__((always_inline)) {
         if (tid == 0) {
@@ -940,6 +949,12 @@ int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
     // 68.6, linear1 233.7 -> 230.9, linear2 208.0 -> 205.3, linear2 dX 225.8 -> 221.4, linear1 dX 206.6 -> 203.1, in_proj dX
     // 162.0 -> 161.6; training step 33.26-33.38 -> 32.86-32.89 ms (three alternating pairs of runs on one box).
     // SFCVIT_GEMM_STAGGER="slots,ticks" (10 ns) overrides; "1,0" = off.
+    // Tile walk: column windows of 6 tiles for the wide GEMMs (N >= 1 792).  An XCD's 32 concurrent tiles are then ~5 row tiles x
+    // 6 column tiles instead of ~3 x 9-12, i.e. 11 distinct operand panels instead of 12-15: memory-side fetch of the N = 3 072 /
+    // 2 304 forward GEMMs 427 -> 263 MB per launch, L2 hit rate 0.56 -> 0.63, time unchanged (profiles/r4/gemm_tile_walk_ab.txt).
+    // SFCVIT_GEMM_WALK = window width, 0 = row-major walk (round 3).
+    static const int walk_env = [] { const char *w = getenv("SFCVIT_GEMM_WALK"); return w ? atoi(w) : -1; }();
+    const int walk = walk_env >= 0 ? walk_env : (a.N / 256 > 6 ? 6 : 0);
     int stag_slots = 4, stag_ticks = 200;
     if (const char *st = getenv("SFCVIT_GEMM_STAGGER")) sscanf(st, "%d,%d", &stag_slots, &stag_ticks);
     if (stag_slots < 1) stag_slots = 1;
@@ -949,13 +964,13 @@ int launch(const sfcvit_gemm_args &a, int grid, hipStream_t s) {
     }
     if (!(e && e[0] == '0')) {
         if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK, true>), LDS_MAX, "gemm8p attribute")) return rc;
-        hipLaunchKernelGGL((gemm8p_kernel<NI, MASK, true>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters, stag_slots, stag_ticks);
+        hipLaunchKernelGGL((gemm8p_kernel<NI, MASK, true>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters, stag_slots, stag_ticks, walk);
         const int rc = check_launch("gemm8p");
         if (rc) (void)hipMemsetAsync(counters, 0, SLOT_UINTS * sizeof(unsigned), s);
         return rc;
     }
     if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&gemm8p_kernel<NI, MASK>), LDS_MAX, "gemm8p attribute")) return rc;
-    hipLaunchKernelGGL((gemm8p_kernel<NI, MASK>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters, stag_slots, stag_ticks);
+    hipLaunchKernelGGL((gemm8p_kernel<NI, MASK>), dim3(grid), dim3(T), LDS_TOTAL, s, a, counters, stag_slots, stag_ticks, walk);
     const int rc = check_launch("gemm8p");
     if (rc) (void)hipMemsetAsync(counters, 0, SLOT_UINTS * sizeof(unsigned), s);   // a launch that did not run leaves no debt
     return rc;
