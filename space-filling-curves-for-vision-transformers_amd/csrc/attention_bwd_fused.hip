@@ -4,8 +4,9 @@
 // exp / dropout-hash / dS arithmetic once instead of twice, and q, k, v, dO read from HBM once instead of twice.
 //
 //   * one workgroup of 16 waves per (batch, head); Q, dO and K of the whole sequence are staged once into LDS by
-//     LDS-DMA (3 x 28 KiB at N = 196); every KEY wave (wave w < nf owns the 16 keys 16w .. 16w+15) fetches its K / V
-//     fragments straight into registers, so V never touches LDS.
+//     LDS-DMA (3 x 28 KiB at N = 196); every KEY wave (wave w < nf owns the 16 keys 16w .. 16w+15) fetches its V
+//     fragments straight into registers, so V never touches LDS (its K fragments are read from the K image where they are
+//     used: held in registers for a whole item they were the eight registers the persistent loop did not have).
 //   * the sequence is walked in chunks of 32 queries.  In chunk c a key wave computes S^T and dP^T of its keys against
 //     the chunk's queries (key on the MFMA lane: the accumulators are the B operands of the dV and dK products without
 //     any data movement), turns them into P and dS, adds P^T dO into dV and dS^T Q into dK -- exactly the loop body of
@@ -20,11 +21,11 @@
 //     (the two-kernel form runs a separate pass over dO and O for it), and -- when the caller asks -- the column sums
 //     of dQ, dK, dV over the sequence (= this (batch, head)'s contribution to the in_proj bias gradient,
 //     torch:nn/functional.py:5822-5833) leave the kernel as 192 floats instead of being re-read from the 231 MB dqkv
-//     tensor by a column-sum pass.
+//     tensor by a column-sum pass (dQ's from the key waves: sum_q dQ[q, :] = scale sum_k (sum_q dS[q, k]) K[k, :]).
 //   * PERSISTENT with a rolling prefetch (round 4): the grid is one workgroup per CU and a workgroup walks (batch, head)
 //     items i, i + grid, ...  While it computes an item it stages the NEXT one behind itself: the Q / dO rows of chunk
 //     c - 1 are dead once step c - 1 has passed its barrier, so step c issues the LDS-DMA of the next item's rows into the
-//     same place; the next K goes into a second K image (all of it in step 0), and in the last step -- dQ waves only,
+//     same place; the next K goes into a second K image (all of it in step 1), and in the last step -- dQ waves only,
 //     the key waves are idle -- the key waves fetch the next V fragments, the O pieces for delta, lse and the row keys.
 //     Every barrier drains the DMA issued a whole step earlier.  The 117 KiB load burst that opened every workgroup
 //     (28 % of the kernel: ~11 B/clock per CU whatever the other CUs do, nothing to overlap it with at one workgroup per
