@@ -92,7 +92,7 @@ __device__ __forceinline__ bf16x8 ds_tr_frag(const char *slot, int key0, int lan
 // NFC: number of 16-row fragments at compile time (0 = from N); DROP: dropout on the probabilities (compile-time: a
 // runtime flag put a branch around every hash, each one a scheduling barrier between the MFMAs).
 template <int NFC, bool DROP>
-__global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_attn_args a, int npad, int stag_round, int stag_per, int stag_ticks, int dq_sums, int items, int nt) {
+__global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_attn_args a, int npad, int stag_round, int stag_per, int stag_ticks, int dq_sums, int items, int nt, unsigned *__restrict__ qcnt) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stagger_start(stag_round, stag_per, stag_ticks);
@@ -195,7 +195,14 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         rec[1] = reinterpret_cast<unsigned long long>(static_cast<const uint16_t *>(a.dout) + size_t(b) * N * D + h * HD);
         rec[2] = reinterpret_cast<unsigned long long>(static_cast<uint16_t *>(a.dqkv) + size_t(b) * N * ld + h * HD);
     };
+    // Items: the first is blockIdx.x; the others come from a counter (qcnt[0], + gridDim.x) that thread 0 draws ONE ITEM AHEAD
+    // of where the number is needed and publishes in the next item's record, so that a workgroup which starts late -- RCCL
+    // kernels hold some CUs while gradients are reduced beside backward -- just takes fewer items; with a fixed stride it would
+    // run its whole list after the others had finished theirs (the case tools/bench_busy_cus.py makes for the GEMM).  qcnt[1]
+    // counts finished workgroups, the last one zeroes both words for the next launch.  qcnt = nullptr: fixed stride.
     int item = blockIdx.x, cur = 0;
+    unsigned drawn = 0;                               // thread 0: the draw in flight
+    if (qcnt && tid == 0) drawn = atomicAdd(qcnt, 1u);
     {   // ---- the first item: everything staged up front ----
         const int b = item / a.H, h = item - b * a.H;
         const uint16_t *base = static_cast<const uint16_t *>(a.qkv) + size_t(b) * N * ld + h * HD;
@@ -218,14 +225,21 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
 
   for (;;) {                                          // ---- items of this workgroup ----
     const int b = item / a.H, h = item - b * a.H;
-    const int nxt = item + gridDim.x;
-    const bool has_next = nxt < items;
+    int nxt = items;                                  // known to every thread after step 0's barrier (record word 3)
+    bool has_next = false;
     char *kimg = kimg0 + cur * npad * 128, *knext = kimg0 + (cur ^ 1) * npad * 128;
     char *small = small0 + cur * 3 * npad * 4, *small_next = small0 + (cur ^ 1) * 3 * npad * 4;
     const float *lse_s = reinterpret_cast<const float *>(small), *del_s = lse_s + npad;
     const uint32_t *rkey_s = reinterpret_cast<const uint32_t *>(small) + 2 * npad;
     unsigned long long *rec = rec0 + cur * 4, *rec_next = rec0 + (cur ^ 1) * 4;
-    if (has_next && tid == 0) write_record(nxt, rec_next);           // read from step 1 on (step 0's barrier in between)
+    if (tid == 0) {                                   // read from step 1 on (step 0's barrier in between)
+        const int nx = qcnt ? int(gridDim.x + drawn) : item + int(gridDim.x);
+        rec_next[3] = (unsigned long long)nx;
+        if (nx < items) {
+            write_record(nx, rec_next);
+            if (qcnt) drawn = atomicAdd(qcnt, 1u);    // for the item after that one: consumed a whole item later
+        }
+    }
     // (the K fragments of this wave's keys are read from the K image where they are used, twice per step: held in registers
     // for the whole item they were the 8 registers the persistent loop did not have)
     f32x4 dk[4], dv[4];
@@ -395,6 +409,10 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
         }
         if (!is_dq) dma_wait();                       // this step's DMA has landed (a key wave has no other vector-memory operation in flight)
         __syncthreads();
+        if (c == 0) {
+            nxt = __builtin_amdgcn_readfirstlane(int(rec_next[3]));
+            has_next = nxt < items;
+        }
         ATRACE(tr_i + 1 + c);
     }
     // The last step: dQ of the last chunk by the two dQ waves.  The key waves are idle and fetch what the next item needs in
@@ -513,6 +531,10 @@ __global__ __launch_bounds__(FT) void attn_seq_bwd_fused_kernel(const sfcvit_att
     item = nxt;
     cur ^= 1;
   }
+    if (qcnt && tid == 0) {
+        const unsigned old = atomicAdd(qcnt + 1, 1u);
+        if (old == gridDim.x - 1u) { qcnt[0] = 0u; qcnt[1] = 0u; }
+    }
 }
 
 constexpr int FUSED_MAX_N = 32 * FMAXC;
@@ -521,8 +543,14 @@ constexpr int FUSED_MAX_LDS = FUSED_MAX_N * FUSED_ROW_BYTES + FUSED_EXTRA + FUSE
 template <int NFC, bool DROP>
 int launch_fused(const sfcvit_attn_args &a, int npad, size_t lds, int grid, int round, int per, int ticks, int dq_sums, hipStream_t s) {
     static const int nt = [] { const char *e = getenv("SFCVIT_ATTN_NT"); return e ? atoi(e) : 0; }();
+    static const int fixed = [] { const char *e = getenv("SFCVIT_ATTN_BWD_QUEUE"); return e && e[0] == '0'; }();     // "0": fixed stride (A/B)
+    unsigned *qcnt = nullptr;
+    if (!fixed && grid < a.B * a.H) {
+        unsigned *slot = stream_counters(s);
+        if (slot) qcnt = slot + 12;
+    }
     if (int rc = raise_lds_limit(reinterpret_cast<const void *>(&attn_seq_bwd_fused_kernel<NFC, DROP>), FUSED_MAX_LDS, "attention_bwd_fused attribute")) return rc;
-    hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<NFC, DROP>), dim3(grid), dim3(FT), lds, s, a, npad, round, per, ticks, dq_sums, a.B * a.H, nt & 1);
+    hipLaunchKernelGGL((attn_seq_bwd_fused_kernel<NFC, DROP>), dim3(grid), dim3(FT), lds, s, a, npad, round, per, ticks, dq_sums, a.B * a.H, nt & 1, qcnt);
     return check_launch("attention_bwd_fused");
 }
 

@@ -19,6 +19,9 @@ void clear_error();
 int check_launch(const char *what);
 // Compute units of the current device (0 if unknown): the grid of the persistent kernels.
 int device_cu_count();
+// gemm8p.hip: 16 zero-initialised device words per (device, stream), shared by the persistent kernels (each leaves its words
+// zero); allocated at the first call on a device (not inside a hipGraph capture: warm up first).  nullptr if unavailable.
+unsigned *stream_counters(void *stream);
 // Opt a kernel into `bytes` of dynamic LDS on the current device (once per kernel and device; 0 or an error code).
 int raise_lds_limit(const void *kernel, int bytes, const char *what);
 

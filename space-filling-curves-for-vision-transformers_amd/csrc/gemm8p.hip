@@ -997,6 +997,10 @@ int launch_mask(const sfcvit_gemm_args &a, int mask, int grid, hipStream_t s) {
 }  // namespace p8
 }  // namespace
 
+// The (device, stream) slot of zero-initialised counters (16 words; this file's kernels use words 0-8 and leave them zero) for
+// other persistent kernels of the library: attention_bwd_fused.hip deals its items from words 12-13.  nullptr: none to be had.
+unsigned *stream_counters(void *stream) { return p8::queue_counters(static_cast<hipStream_t>(stream)); }
+
 // Weight-gradient form (both operands k-major, split-K into the workspace slabs).  Returns -1 when not eligible,
 // else a status; *splits_used = number of slabs written (the caller runs the ordered reduction over them).
 // k need not be a multiple of 128 (k = batch x tokens: 19 600 rows at batch 100): the kernel takes the largest multiple,
