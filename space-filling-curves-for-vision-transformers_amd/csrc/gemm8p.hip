@@ -1013,7 +1013,12 @@ int gemm8p_km_dispatch(const sfcvit_gemm_args &a, int splits_req, int *splits_us
     if (!cus) return -1;
     const int Kb = a.K / 128 * 128, tail = a.K - Kb;
     const int tiles = (a.M / 256) * (a.N / 256), KT = Kb / 64;
-    int splits = cus / tiles;                                     // one workgroup per CU
+    // SFCVIT_RESERVE_CUS=n (read per call): leave n CUs out of the split, for nodes where collectives run beside backward -- a
+    // launch of one workgroup per CU takes twice as long when it does not fit on the CUs that are free
+    int reserve = 0;
+    if (const char *rv = getenv("SFCVIT_RESERVE_CUS")) reserve = atoi(rv);
+    if (reserve < 0 || reserve > cus / 2) reserve = 0;
+    int splits = (cus - reserve) / tiles;                         // one workgroup per CU
     if (splits > splits_req) splits = splits_req;
     const int64_t slabs_avail = a.workspace_bytes / (int64_t(a.M) * a.N * int64_t(sizeof(float))) - (tail ? 1 : 0);
     if (splits > slabs_avail) splits = int(slabs_avail);
