@@ -474,6 +474,25 @@ def test_full_size_logits_loss_and_grads(name, golden_dir):
     print(f"[rounding-point parity] {name}: max|dlogit|/max|logit| = {r_err:.2e}, |dloss| = {abs(float(loss.detach()) - float(r_loss)):.2e}, "
           f"worst gradient cosine = {r_worst[0]:.5f} ({r_worst[1]})")
     assert r_err <= R_LOGIT_TOL, (name, r_err)
+    # ... and the HIP path is no further from the fp32 oracle than bf16 storage alone puts the rounding-point oracle (plus a
+    # small allowance): the fp32 bars above (3e-2, cosine 0.99) are loose for ViT-L and tight for ViT-Tiny only because the
+    # forward's rounding noise differs by model; this one calibrates itself
+    o_err = float((r_logits - ref_logits).abs().max() / scale)
+    assert err <= o_err + 4e-3, (name, err, o_err)                    # measured: +1.2e-3 at most (profiles/r4/rounding_point_parity.txt)
+    margin = (1.0, "")
+    for k, p in model.named_parameters():
+        if k.startswith("mlp_mixer.token_mix"):
+            continue
+        r32, rr = leaves[k].grad.flatten(), rleaves[k].grad.flatten()
+        if float(r32.norm()) < 1e-7:
+            continue
+        g = p.grad.float().cpu().flatten()
+        cos_o = float(torch.dot(rr, r32) / (rr.norm() * r32.norm() + 1e-30))
+        cos_h = float(torch.dot(g, r32) / (g.norm() * r32.norm() + 1e-30))
+        margin = min(margin, (cos_h - cos_o, k))
+        assert cos_h >= cos_o - 2e-3, (name, k, cos_h, cos_o)          # measured: -1.0e-3 at most
+    print(f"[self-calibrated] {name}: logits HIP vs fp32 {err:.2e}, rounding-point oracle vs fp32 {o_err:.2e}; smallest "
+          f"(HIP cosine - oracle cosine) against fp32 = {margin[0]:+.4f} ({margin[1]})")
     assert abs(float(loss.detach()) - float(r_loss)) <= 2e-3 * abs(float(r_loss)) + 1e-3, (name, float(loss.detach()), float(r_loss))
     assert r_worst[0] >= R_COS, (name, r_worst)
 
