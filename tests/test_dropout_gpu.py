@@ -135,6 +135,7 @@ def test_encoder_layer_training_mode_against_masked_reference(ops, B, N, D, H, F
     ops.KERNEL_LOG = []
     try:
         y = F._EncoderLayer.apply(*leaves, H, 1e-5, p, seeds, None)        # scale None = 1 / sqrt(head dim)
+        kept = [t.detach() for t in y.grad_fn.saved_tensors[:10]]           # (freed by backward)
         y.backward(dy)
         ran = set(ops.KERNEL_LOG)
     finally:
@@ -173,6 +174,36 @@ def test_encoder_layer_training_mode_against_masked_reference(ops, B, N, D, H, F
         cos = float(torch.dot(gg, rr) / (gg.norm() * rr.norm() + 1e-30))
         assert cos > 0.99, (name, cos)
         assert abs(float(gg.norm() / rr.norm()) - 1) < 5e-2, name
+
+    # ---- every bf16 store of the training-mode layer, bit level (round 4): the saved tensors of the product's autograd
+    # Function against fp32 math on the HIP path's own inputs to each store, with the same masks and the kernels' order of
+    # operations (dropout scales the biased / activated accumulator, the residual comes last; the attention probabilities are
+    # masked and scaled, then rounded to bf16 for P V, and divided by the fp32 row sum of the UNMASKED numerators): equal except
+    # where an fp32 last bit crossed a rounding boundary, then one bf16 step apart (tests/test_parity_gpu.py: _store_point)
+    from test_parity_gpu import _store_point
+    rb = lambda t: t.to(torch.bfloat16).float()                                   # noqa: E731
+    cpu = lambda t: t.detach().float().cpu()                                       # noqa: E731
+    x2, qkv_s, o_s, _, s1_s, _, _, x1_s, h_s, s2_s = kept
+    W = {k: cpu(v) for k, v in P.items()}
+    ks = float(torch.tensor(1.0, dtype=torch.float32) / (torch.tensor(1.0, dtype=torch.float32) - torch.tensor(p, dtype=torch.float32)))
+    keep = lambda m: (cpu(m) > 0).float() * ks                                     # noqa: E731
+    rep = []
+    _store_point("qkv", qkv_s, rb(cpu(x2) @ W["in_w"].t() + W["in_b"]), rep, 1e-3)
+    qf = cpu(qkv_s).view(B, N, 3 * D)
+    qh, kh, vh = (qf[..., i * D:(i + 1) * D].reshape(B, N, H, hd).transpose(1, 2) for i in range(3))
+    sc = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
+    e = torch.exp(sc - sc.amax(-1, keepdim=True))
+    pm = rb(e * keep(ma))
+    o_ref = rb(((pm @ vh) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(M, D))
+    p_abs = (((e * keep(ma)) / e.sum(-1, keepdim=True)) @ vh.abs()).transpose(1, 2).reshape(M, D)
+    _store_point("attention (dropout on P)", o_s.reshape(M, D), o_ref, rep, 2e-3, slack=2.0 ** -8 * p_abs)
+    _store_point("out_proj, dropout1, + x", s1_s, rb((cpu(o_s).view(M, D) @ W["out_w"].t() + W["out_b"]) * keep(m1).view(M, D) + cpu(x2)), rep, 1e-3)
+    ln = lambda t, w_, b_: torch.nn.functional.layer_norm(t, (D,), w_, b_, 1e-5)    # noqa: E731
+    _store_point("LN1", x1_s, rb(ln(cpu(s1_s), W["n1_w"], W["n1_b"])), rep, 1e-3)
+    _store_point("relu(linear1), dropout", h_s, rb(torch.relu(cpu(x1_s) @ W["w1"].t() + W["b1"]) * keep(mf).view(M, Fd)), rep, 1e-3)
+    _store_point("linear2, dropout2, + x1", s2_s, rb((cpu(h_s) @ W["w2"].t() + W["b2"]) * keep(m2).view(M, D) + cpu(x1_s)), rep, 1e-3)
+    _store_point("LN2", y.view(M, D), rb(ln(cpu(s2_s), W["n2_w"], W["n2_b"])), rep, 1e-3)
+    print("[training-mode store points] " + ", ".join(f"{t} {f:.1e}" for t, f, _ in rep))
 
 
 def test_model_train_vs_eval_modes():
