@@ -922,3 +922,24 @@ def test_hier_resample_concat_is_torch_linear_interpolation(ops, counts, D, B):
     for got, leaf in zip(grads, leaves):
         assert got.shape == leaf.shape
         assert (got.float() - leaf.grad).abs().max() <= 1e-2 * leaf.grad.abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K,akm,bkm", [(12544, 768, 768, False, False), (12544, 3072, 768, False, False), (4096, 768, 3072, False, False),
+                                           (768, 2304, 12544, True, True), (1000, 264, 200, False, False), (392, 768, 768, False, True)])
+def test_gemm_results_are_the_correctly_rounded_fp32_sums(ops, M, N, K, akm, bkm):
+    """Bit level, not tolerance: every GEMM family (persistent forward / dX, the k-major weight-gradient kernel with its fp32
+    split-K slabs, the older kernels for odd shapes) stores the bf16 rounding of the fp32 sum -- equal to rounding torch's
+    fp32 product of the same bf16 operands except where the two summation orders' last bits straddle a rounding boundary
+    (then adjacent bf16 values): <= 1e-3 of the elements, none further than one step."""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    a = bf(torch.randn((K, M) if akm else (M, K), device="cuda", generator=g))
+    b = bf(torch.randn((K, N) if bkm else (N, K), device="cuda", generator=g) * K ** -0.5)
+    bias = bf(torch.randn(N, device="cuda", generator=g) * 0.1) if not (akm or bkm) else None
+    got = ops.gemm(a, b, a_kmajor=akm, b_kmajor=bkm, bias=bias).float()
+    ref = (a.float().t() if akm else a.float()) @ (b.float() if bkm else b.float().t())
+    if bias is not None:
+        ref = ref + bias.float()
+    ref = ref.to(torch.bfloat16).float()
+    d = (got - ref).abs()
+    assert (d <= 2.0 ** -7 * torch.maximum(got.abs(), ref.abs()) + 1e-5 * ref.abs().max()).all(), float(d.max())
+    assert float((d > 0).float().mean()) <= 1e-3, (ops.last_gemm_kernel(), float((d > 0).float().mean()))
