@@ -943,3 +943,40 @@ def test_gemm_results_are_the_correctly_rounded_fp32_sums(ops, M, N, K, akm, bkm
     d = (got - ref).abs()
     assert (d <= 2.0 ** -7 * torch.maximum(got.abs(), ref.abs()) + 1e-5 * ref.abs().max()).all(), float(d.max())
     assert float((d > 0).float().mean()) <= 1e-3, (ops.last_gemm_kernel(), float((d > 0).float().mean()))
+
+
+@pytest.mark.parametrize("B,H,N,p", [(3, 4, 196, 0.1), (2, 2, 196, 0.0), (2, 3, 64, 0.1), (1, 2, 576, 0.1)])
+def test_attention_backward_against_fp32_math_with_the_kernel_roundings(ops, B, H, N, p):
+    """dQ | dK | dV of the attention backward (one-pass kernel for N <= 224, sequence-resident kernels above) against fp32
+    math that rounds where the kernels round -- P (masked, scaled) and dS to bf16 before their MFMA products, fp32 sums, one
+    bf16 rounding of each result -- from the forward's own lse and the same dropout mask.  Each output is two roundings deep
+    (like the forward's, tests/test_parity_gpu.py), so the allowance on top of one bf16 step is every P / dS of the sum one
+    step off: 2^-8 sum |terms| (used: <= 0.35 of it); at most 5e-3 of the elements differ at all (measured: 4e-5 .. 1.7e-3)."""
+    hd, D = 64, H * 64
+    g = torch.Generator(device="cuda").manual_seed(23)
+    qkv = bf(torch.randn(B, N, 3 * D, device="cuda", generator=g))
+    dout = bf(torch.randn(B, N, D, device="cuda", generator=g))
+    seed = 77
+    out, lse = ops.attention_fwd(qkv, H, p, seed)
+    dqkv = ops.attention_bwd(qkv, out, lse, dout, H, p, seed).float()
+    rb = lambda t: t.to(torch.bfloat16).float()                                   # noqa: E731
+    sp = lambda t: t.reshape(B, N, H, hd).transpose(1, 2)                          # noqa: E731
+    q, k, v = (sp(t) for t in qkv.float().split(D, dim=-1))
+    do, o = sp(dout.float()), sp(out.float())
+    scale = hd ** -0.5
+    ks = 1.0 / (1.0 - p)
+    keep = (ops.dropout_mask(B * H * N, N, p, seed).float().view(B, H, N, N) > 0).float() * ks if p > 0 else torch.ones(B, H, N, N, device="cuda")
+    P = torch.exp((q @ k.transpose(-1, -2)) * scale - lse.unsqueeze(-1))           # lse: the forward's, natural log
+    delta = (do * o).sum(-1, keepdim=True)
+    Pm = rb(P * keep)
+    dS = rb(P * ((do @ v.transpose(-1, -2)) * keep - delta))
+    ref = {"dq": (dS @ k) * scale, "dk": (dS.transpose(-1, -2) @ q) * scale, "dv": Pm.transpose(-1, -2) @ do}
+    slack = {"dq": (dS.abs() @ k.abs()) * scale, "dk": (dS.abs().transpose(-1, -2) @ q.abs()) * scale, "dv": Pm.transpose(-1, -2) @ do.abs()}
+    unsp = lambda t: t.transpose(1, 2).reshape(B, N, D)                            # noqa: E731
+    for i, name in enumerate(("dq", "dk", "dv")):
+        got, want = dqkv[..., i * D:(i + 1) * D], rb(unsp(ref[name]))
+        d = (got - want).abs()
+        bound = 2.0 ** -7 * torch.maximum(got.abs(), want.abs()) + 2.0 ** -8 * unsp(slack[name]) + 1e-6
+        assert (d <= bound).all(), (name, ops.last_attn_kernel(), float((d / bound).max()))
+        assert float((d > 0).float().mean()) <= 5e-3, (name, ops.last_attn_kernel(), float((d > 0).float().mean()))
+        print(f"[attention backward, bit level] N={N} p={p} {name}: {float((d > 0).float().mean()):.2e} of the elements differ, worst {float((d / bound).max()):.2f} of the bound [{ops.last_attn_kernel()}]")
