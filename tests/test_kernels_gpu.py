@@ -980,3 +980,33 @@ def test_attention_backward_against_fp32_math_with_the_kernel_roundings(ops, B, 
         assert (d <= bound).all(), (name, ops.last_attn_kernel(), float((d / bound).max()))
         assert float((d > 0).float().mean()) <= 5e-3, (name, ops.last_attn_kernel(), float((d > 0).float().mean()))
         print(f"[attention backward, bit level] N={N} p={p} {name}: {float((d > 0).float().mean()):.2e} of the elements differ, worst {float((d / bound).max()):.2f} of the bound [{ops.last_attn_kernel()}]")
+
+
+@pytest.mark.parametrize("M,D", [(4097, 768), (1000, 1024), (333, 192)])
+def test_rowwise_kernels_store_the_correctly_rounded_value(ops, M, D):
+    """LayerNorm forward / backward (dx, with and without the added residual gradient) and GELU forward / backward at bit
+    level: the bf16 rounding of the fp32 formula on the same bf16 inputs, up to one bf16 step where the fp32 evaluation
+    orders differ (reductions, erf / exp implementations): <= 2e-3 of the elements."""
+    g = torch.Generator(device="cuda").manual_seed(29)
+    x = bf(torch.randn(M, D, device="cuda", generator=g) * 1.5 + 0.3)
+    gamma, beta = bf(1 + 0.2 * torch.randn(D, device="cuda", generator=g)), bf(0.1 * torch.randn(D, device="cuda", generator=g))
+    dy, add = bf(torch.randn(M, D, device="cuda", generator=g)), bf(torch.randn(M, D, device="cuda", generator=g))
+
+    def same(tag, got, ref, frac=2e-3):
+        got, ref = got.float(), ref.to(torch.bfloat16).float()
+        d = (got - ref).abs()
+        assert (d <= 2.0 ** -7 * torch.maximum(got.abs(), ref.abs()) + 1e-5 * ref.abs().max()).all(), (tag, float(d.max()))
+        assert float((d > 0).float().mean()) <= frac, (tag, float((d > 0).float().mean()))
+
+    xf = x.float().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xf, (D,), gamma.float(), beta.float(), 1e-5)
+    ref.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    same("layernorm forward", y, ref.detach())
+    same("layernorm backward dx", ops.layernorm_bwd(dy, x, mean, rstd, gamma)[0], xf.grad)
+    same("layernorm backward dx + add", ops.layernorm_bwd(dy, x, mean, rstd, gamma, dx_add=add)[0], xf.grad + add.float())
+    uf = x.float().requires_grad_(True)
+    gr = torch.nn.functional.gelu(uf)
+    gr.backward(dy.float())
+    same("gelu forward", ops.gelu_fwd(x), gr.detach())
+    same("gelu backward", ops.gelu_bwd(dy, x), uf.grad)
